@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Headline workload (BASELINE.json configs[1]): deferred lighting resolve of a 3840x2160 synthetic
+G-buffer with 256 point lights, 8-bit output, inputs resident in HBM.  One "step" = one resolve of
+one frame.  The 2^22-instance frustum cull (configs[2]) is timed in the same run and reported in
+the "cull" object.  For N > 1 every rank shades its own frame (frame-batch parallelism, no
+collective in the timed region: weak scaling); the screen-band variant of ONE frame with an RCCL
+all_gather of the bands is timed as well and reported under "band_sharded".
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E (spec)
+VALU_FP32_PEAK = 157.3e12  # FLOP/s, vector FP32 (spec)
+
+
+def deferred_algorithmic(width, height, lights):
+    """Algorithmic work of one resolve: 24 B/pixel (20 read + 4 written, 8-bit output) and
+    150 + 117*L FP32 operations per pixel (FMA counted as two)."""
+    px = width * height
+    return px * 24.0, px * (150.0 + 117.0 * lights)
+
+
+def cull_algorithmic(n, visible, meshes):
+    return n * 32.0 + visible * 4.0 + meshes * 20.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--lights", type=int, default=256)
+    ap.add_argument("--instances", type=int, default=1 << 22)
+    ap.add_argument("--meshes", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cull", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    vkr = importlib.import_module("vk-renderer_amd")
+    synth = importlib.import_module("vk-renderer_amd.synth")
+    vdist = importlib.import_module("vk-renderer_amd.dist")
+    ctx = vkr.Context(local_rank)
+    info = ctx.device_info()
+
+    W, H, L = args.width, args.height, args.lights
+    K, WU = args.steps, args.warmup
+
+    # ---------------------------------------------------------------- deferred: frame per rank
+    case = synth.deferred_case(W, H, L, config_index=1 + rank)
+    gb = vkr.GBuffer(ctx, W, H).upload(case["gbuf"])
+    lights = ctx.buffer_from(case["lights"])
+    out = ctx.image(vkr.FORMAT_R8G8B8A8_UNORM, W, H)
+    dargs = vkr.make_deferred_args(gb, out, lights, L, case["push"])
+
+    for _ in range(WU):
+        ctx.deferred_resolve(dargs)
+    ctx.wait_idle()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    ev0 = ctx.marker()
+    for _ in range(K):
+        ctx.deferred_resolve(dargs)
+    ev1 = ctx.marker()
+    ctx.wait_idle()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    wall = t1 - t0
+    kern_ms = ev1.elapsed_ms_since(ev0) / K
+    if world > 1:
+        tt = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt.item())
+    pixels_total = float(W) * H * K * world
+    value = pixels_total / wall / 1e9
+    dbytes, dflops = deferred_algorithmic(W, H, L)
+    ach_flops = dflops / (kern_ms * 1e-3)
+    ach_bytes = dbytes / (kern_ms * 1e-3)
+
+    result = {
+        "metric": "shaded Gpixel/s at 4K x 256 lights (deferred.comp resolve)",
+        "value": value,
+        "unit": "Gpixel/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": WU,
+        "ms_per_step": wall / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"deferred resolve {W}x{H}, {L} point lights, rgba8 output, one frame per GPU per step",
+                   "width": W, "height": H, "lights": L, "parallelism": f"frame-batch x{world}", "device": info["name"]},
+        "roofline": {"bound": "valu_fp32", "kernel": "deferred_kernel", "achieved": ach_flops / 1e12, "peak": VALU_FP32_PEAK / 1e12,
+                     "unit": "TFLOP/s", "frac": ach_flops / VALU_FP32_PEAK, "traffic": None,
+                     "kernel_ms": kern_ms, "algorithmic_flops": dflops, "algorithmic_bytes": dbytes,
+                     "hbm_achieved_GBps": ach_bytes / 1e9, "hbm_frac": ach_bytes / HBM_PEAK},
+    }
+
+    # ---------------------------------------------------------------- deferred: one frame in bands
+    if world > 1:
+        frame = synth.deferred_case(W, H, L, config_index=1)  # the same frame on every rank
+        gb.upload(frame["gbuf"])
+        lights.upload(frame["lights"])
+        r0, r1 = vdist.band_rows(H, world, rank)
+        rows_max = vdist.band_rows(H, world, 0)[1]
+        pitch = out.pitch
+        band_t = torch.zeros(rows_max * pitch, dtype=torch.uint8, device="cuda")
+        full_t = torch.zeros(world * rows_max * pitch, dtype=torch.uint8, device="cuda")
+        band_img = vkr.Image2D(band_t.data_ptr(), W, r1 - r0, pitch, vkr.FORMAT_R8G8B8A8_UNORM)
+        bargs = vkr.make_deferred_args(gb, out, lights, L, frame["push"], row0=r0, rows=r1 - r0)
+        bargs.out = band_img
+
+        def band_step():
+            ctx.deferred_resolve(bargs)
+            ctx.wait_idle()
+            dist.all_gather_into_tensor(full_t, band_t)
+
+        for _ in range(WU):
+            band_step()
+        torch.cuda.synchronize()
+        barrier()
+        tb0 = time.perf_counter()
+        for _ in range(K):
+            band_step()
+        torch.cuda.synchronize()
+        barrier()
+        tb = time.perf_counter() - tb0
+        tt = torch.tensor([tb], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        tb = float(tt.item())
+        result["band_sharded"] = {"value": float(W) * H * K / tb / 1e9, "unit": "Gpixel/s", "ms_per_frame": tb / K * 1e3,
+                                  "scaling": "strong", "collective": "all_gather_into_tensor of rgba8 bands (RCCL)"}
+
+    # ---------------------------------------------------------------- cull
+    if not args.no_cull:
+        N, M = args.instances, args.meshes
+        # rotate through distinct input sets larger than the 256 MiB Infinity Cache in total
+        nsets = 3
+        scenes, css = [], []
+        for s in range(nsets):
+            sc = synth.cull_case(N, M, config_index=2 + 10 * rank + s)
+            scenes.append(sc)
+            css.append(vkr.CullScene(ctx, sc["aabb_min"], sc["aabb_max"], sc["mesh_base"], sc["cmd_template"]))
+        planes = scenes[0]["planes"]
+        cull = {}
+        for mode_name, flags in (("atomic", 0), ("deterministic", vkr.CULL_DETERMINISTIC)):
+            cargs = [cs.args(planes, flags) for cs in css]
+            for i in range(max(WU, nsets)):
+                ctx.prep_indirect(cargs[i % nsets])
+            ctx.wait_idle()
+            torch.cuda.synchronize()
+            barrier()
+            c0 = time.perf_counter()
+            e0 = ctx.marker()
+            for i in range(K):
+                ctx.prep_indirect(cargs[i % nsets])
+            e1 = ctx.marker()
+            ctx.wait_idle()
+            torch.cuda.synchronize()
+            barrier()
+            cw = time.perf_counter() - c0
+            if world > 1:
+                tt = torch.tensor([cw], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                cw = float(tt.item())
+            call_ms = e1.elapsed_ms_since(e0) / K
+            vis = int(css[0].results()["cmds"]["instanceCount"].sum())
+            cb = cull_algorithmic(N, vis, M)
+            cull[mode_name] = {"value": float(N) * K * world / cw / 1e9, "unit": "G instances/s", "ms_per_call": call_ms,
+                               "visible_fraction": vis / N,
+                               "roofline": {"bound": "hbm", "achieved": cb / (call_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
+                                            "unit": "GB/s", "frac": cb / (call_ms * 1e-3) / HBM_PEAK, "traffic": None,
+                                            "algorithmic_bytes": cb}}
+        cull["config"] = {"workload": f"frustum cull + compaction, {N} instance AABBs, {M} meshes, {nsets} rotating input sets",
+                          "parallelism": f"replicated scene x{world}"}
+        result["cull"] = cull
+
+    # ---------------------------------------------------------------- CPU baseline (rank 0, N=1)
+    if world == 1 and not args.no_cpu_baseline:
+        import oracle  # checker/baseline only: never on the measured GPU path
+        oracle.build()
+        cores = min(16, os.cpu_count() or 1)
+        rows = max(8, H // 16)
+        tc0 = time.perf_counter()
+        oracle.deferred(case["gbuf"], case["lights"], case["push"], mode="f32", rows=(0, rows), threads=cores, want=("rgba8",))
+        tc = time.perf_counter() - tc0
+        result["cpu_baseline"] = {"value": float(W) * rows / tc / 1e9, "unit": "Gpixel/s", "cores": cores, "kind": "port",
+                                  "sample": f"rows 0..{rows} of the same {W}x{H} frame, {L} lights, binary32 C restatement of deferred.comp, {cores} threads",
+                                  "seconds": tc}
+        if not args.no_cull:
+            sc = scenes[0]
+            tc0 = time.perf_counter()
+            oracle.cull(sc["aabb_min"], sc["aabb_max"], planes, sc["mesh_base"], sc["cmd_template"], want_mask=False)
+            tc = time.perf_counter() - tc0
+            result["cull"]["cpu_baseline"] = {"value": float(N) / tc / 1e9, "unit": "G instances/s", "cores": 1, "kind": "port",
+                                              "sample": f"all {N} instances, scalar C restatement", "seconds": tc}
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

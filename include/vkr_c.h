@@ -1,0 +1,244 @@
+/*
+ * vkr_c.h - C ABI of the MI355X (gfx950, HIP) implementation of vk-renderer's two
+ * compute passes: the deferred lighting resolve and the frustum cull / indirect
+ * command compaction.
+ *
+ * Every function returns a vkr_status (0 = OK).  No C++ exceptions cross this ABI;
+ * vkr_last_error() returns the message of the calling thread's last failure.
+ * All pointers named `device` are HIP device pointers (hipMalloc'd, or any memory
+ * the GPU can address); they may come from vkr_buffer_* or from the caller's own
+ * allocator (e.g. a torch tensor's data_ptr()).
+ *
+ * A context owns one HIP stream on one GPU and is NOT thread-safe, exactly like
+ * the reference's single-threaded wrappers (VMA is created externally
+ * synchronised at /root/reference/src/vkmemory.cpp:176; one command pool per
+ * queue without locks at /root/reference/inc/vkcore.hpp:124-168).
+ *
+ * Each entry point names the reference interface it replaces.
+ */
+#ifndef VKR_C_H_
+#define VKR_C_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VKR_API __attribute__((visibility("default")))
+
+typedef enum vkr_status {
+  VKR_OK = 0,
+  VKR_ERR_INVALID_ARGUMENT = 1,
+  VKR_ERR_OUT_OF_MEMORY = 2,
+  VKR_ERR_DEVICE = 3,      /* a HIP call failed; see vkr_last_error() */
+  VKR_ERR_NOT_FOUND = 4,   /* unknown kernel name */
+  VKR_ERR_NOT_READY = 5,   /* fence not signalled yet (status query / timed-out wait) */
+  VKR_ERR_BAD_STATE = 6,   /* command list used out of order */
+  VKR_ERR_UNSUPPORTED = 7
+} vkr_status;
+
+/* Image formats use the numeric values of VkFormat so that host code written against
+ * the reference (vk::Format at /root/reference/src/main.cpp:112-117) ports unchanged. */
+typedef enum vkr_format {
+  VKR_FORMAT_UNDEFINED = 0,
+  VKR_FORMAT_R8G8B8A8_UNORM = 37,
+  VKR_FORMAT_B8G8R8A8_UNORM = 44, /* accepted for the output image; bytes are written in RGBA order, as the
+                                     reference's rgba8-declared store does into its BGRA swapchain image */
+  VKR_FORMAT_R16G16B16A16_SFLOAT = 97,
+  VKR_FORMAT_R32_SFLOAT = 100,
+  VKR_FORMAT_R32G32B32A32_SFLOAT = 109,
+  VKR_FORMAT_D32_SFLOAT = 126
+} vkr_format;
+
+typedef struct vkr_context vkr_context;
+typedef struct vkr_buffer vkr_buffer;
+typedef struct vkr_kernel vkr_kernel;
+typedef struct vkr_cmd vkr_cmd;
+typedef struct vkr_fence vkr_fence;
+
+/* ------------------------------------------------------------------ context / errors */
+
+/* Replaces vw::Instance + vw::Device bring-up (/root/reference/inc/vkcore.hpp:186-218) and the
+ * process-global vw::g::device (/root/reference/src/vkcore.cpp:4-10): one context per GPU. */
+VKR_API int32_t vkr_context_create(int32_t device_ordinal, vkr_context** out_ctx);
+VKR_API int32_t vkr_context_destroy(vkr_context* ctx);
+/* Message of the calling thread's most recent failing call ("" if none). */
+VKR_API const char* vkr_last_error(void);
+/* Fills a NUL-terminated description "<name> <gcn arch> CUs=<n> clock=<MHz>". */
+VKR_API int32_t vkr_context_device_info(vkr_context* ctx, char* out, size_t out_bytes, int32_t* out_cu_count,
+                                         int32_t* out_clock_mhz);
+/* The HIP stream (hipStream_t) all work of this context is ordered on. */
+VKR_API int32_t vkr_context_stream(vkr_context* ctx, void** out_hip_stream);
+
+/* ------------------------------------------------------------------ memory
+ * Replaces vw::MemoryAllocator / vw::Buffer / vw::Image / vw::StagingBuffer
+ * (/root/reference/inc/vkmemory.hpp:25-219): VMA allocations become hipMalloc (device) or pinned
+ * host memory mapped into the device (the CPU_TO_GPU persistently-mapped case,
+ * /root/reference/src/vkmemory.cpp:34-45). */
+#define VKR_BUFFER_DEVICE 0u       /* VMA_MEMORY_USAGE_GPU_ONLY */
+#define VKR_BUFFER_HOST_VISIBLE 1u /* VMA_MEMORY_USAGE_CPU_TO_GPU: persistently mapped */
+
+VKR_API int32_t vkr_buffer_create(vkr_context* ctx, uint64_t bytes, uint32_t flags, vkr_buffer** out_buf);
+/* Wraps memory the caller owns; destroy only drops the handle. */
+VKR_API int32_t vkr_buffer_wrap(vkr_context* ctx, void* device_ptr, uint64_t bytes, vkr_buffer** out_buf);
+VKR_API int32_t vkr_buffer_destroy(vkr_buffer* buf);
+VKR_API int32_t vkr_buffer_size(vkr_buffer* buf, uint64_t* out_bytes);
+/* Host pointer of a HOST_VISIBLE buffer (vw::Buffer::copyToMapped's mMappedPtr). */
+VKR_API int32_t vkr_buffer_map(vkr_buffer* buf, void** out_host_ptr);
+VKR_API int32_t vkr_buffer_device_ptr(vkr_buffer* buf, void** out_device_ptr);
+/* Stream-ordered copies (vw::StagingBuffer::queueBufferCopy + flush); the host range must stay
+ * valid until the next fence wait / wait_idle. */
+VKR_API int32_t vkr_buffer_upload(vkr_buffer* buf, uint64_t offset, const void* src, uint64_t bytes);
+VKR_API int32_t vkr_buffer_download(vkr_buffer* buf, uint64_t offset, void* dst, uint64_t bytes);
+VKR_API int32_t vkr_buffer_fill_u32(vkr_buffer* buf, uint64_t offset, uint32_t value, uint64_t bytes);
+
+/* ------------------------------------------------------------------ typed entry points */
+
+typedef struct vkr_image2d {
+  void* device;         /* first texel of row 0 */
+  uint32_t width;       /* texels */
+  uint32_t height;      /* rows */
+  uint32_t pitch_bytes; /* >= 16-byte-aligned row size; rows must start 16-byte aligned */
+  uint32_t format;      /* vkr_format */
+} vkr_image2d;
+
+#define VKR_LIGHT_STRIDE 48u /* std140 Light record, /root/reference/shaders/deferred.comp:12-19 */
+
+#define VKR_DEFERRED_RADIUS_CUTOFF 1u /* extension: a light contributes only where dist^2 < pointLightRadius^2
+                                         (push[3]); enables per-tile light lists.  Off = reference behaviour
+                                         (pointLightRadius is pushed but never read, deferred.comp:8,120-129). */
+
+/* One dispatch of /root/reference/shaders/deferred.comp (main, :98-131) as recorded at
+ * /root/reference/src/main.cpp:222-226.  Bindings follow main.cpp:163-167,190-196:
+ * samplers[0..3] = albedo, material ("gSpecular"), normal, depth; UBO = lights; outTex = out. */
+typedef struct vkr_deferred_args {
+  vkr_image2d albedo;   /* R8G8B8A8_UNORM   (.rgb) */
+  vkr_image2d material; /* R8G8B8A8_UNORM   (.g roughness, .b metalness) */
+  vkr_image2d normal;   /* R16G16B16A16_SFLOAT (.rgb, un-normalised) */
+  vkr_image2d depth;    /* D32_SFLOAT / R32_SFLOAT */
+  vkr_image2d out;      /* R8G8B8A8_UNORM (reference), or R16G16B16A16_SFLOAT / R32G32B32A32_SFLOAT
+                           (pre-quantisation colour, alpha = 1) */
+  const void* lights;   /* device: light_count records of VKR_LIGHT_STRIDE bytes */
+  uint32_t light_count;
+  float push[20];       /* DeferredPushData, 80 bytes (/root/reference/src/main.cpp:76-80):
+                           cameraPos @0, pointLightRadius @12, inverseVP @16 column-major */
+  /* Screen-band sharding: the five images hold rows [row_offset, row_offset+height) of a frame
+   * full_height rows tall (UV is computed against the full frame).  0/0 = whole frame. */
+  uint32_t row_offset;
+  uint32_t full_height;
+  uint32_t flags;
+  uint32_t reserved;
+} vkr_deferred_args;
+
+VKR_API int32_t vkr_deferred_resolve(vkr_context* ctx, const vkr_deferred_args* args);
+
+/* VkDrawIndexedIndirectCommand, 20 bytes, one per mesh
+ * (/root/reference/src/vkmodel.cpp:79,96; consumed at /root/reference/inc/vkmodel.hpp:72). */
+typedef struct vkr_draw_indexed_indirect_command {
+  uint32_t indexCount;
+  uint32_t instanceCount;
+  uint32_t firstIndex;
+  int32_t vertexOffset;
+  uint32_t firstInstance;
+} vkr_draw_indexed_indirect_command;
+
+#define VKR_CULL_DETERMINISTIC 1u /* visible[] ascending inside each mesh segment (count -> scan -> scatter);
+                                     default is one atomic per wave and mesh run (segment order unspecified) */
+
+/* The pass /root/reference/shaders/prep_indirect.comp:1-5 leaves empty.  Instance i carries a
+ * world-space AABB and a mesh id; instances of a mesh are contiguous, as the model-matrix array of
+ * /root/reference/src/vkmodel.cpp:108-110 is (PerMeshData::modelMatrixBaseIndex,
+ * /root/reference/inc/vkmodel.hpp:76-78).  An instance is visible iff for all six planes
+ * ((n.x*p.x + n.y*p.y) + n.z*p.z) + n.w >= 0 at the AABB's p-vertex, in binary32 without fused
+ * multiply-add.  Results: cmd_out[m] = cmd_template[m] with instanceCount = visible instances of
+ * mesh m and firstInstance = first_instance + mesh_base[m]; visible[mesh_base[m] + k] = global
+ * index (first_instance + i) of the k-th visible instance of mesh m. */
+typedef struct vkr_cull_args {
+  const void* aabb_min;     /* device: N x float4, xyz = min corner, w = mesh id (uint32 bits) */
+  const void* aabb_max;     /* device: N x float4, xyz = max corner, w ignored */
+  uint64_t instance_count;  /* N (< 2^31) */
+  float planes[24];         /* six float4, see vkr_frustum_planes */
+  const uint32_t* mesh_base;                               /* device: M entries, local to this call */
+  uint32_t mesh_count;                                     /* M */
+  uint32_t first_mesh;      /* instance-range sharding: mesh ids in aabb_min.w are global, this call owns
+                               meshes [first_mesh, first_mesh + M) */
+  uint32_t first_instance;  /* global index of local instance 0 */
+  uint32_t flags;
+  const vkr_draw_indexed_indirect_command* cmd_template;   /* device: M */
+  vkr_draw_indexed_indirect_command* cmd_out;              /* device: M */
+  uint32_t* visible;        /* device: N */
+  uint32_t* error_flag;     /* device, optional: set to 1 if an instance names a mesh outside this call */
+  void* workspace;          /* device, VKR_CULL_DETERMINISTIC only */
+  uint64_t workspace_bytes; /* >= vkr_cull_workspace_bytes(N, M) */
+} vkr_cull_args;
+
+VKR_API int32_t vkr_prep_indirect(vkr_context* ctx, const vkr_cull_args* args);
+VKR_API uint64_t vkr_cull_workspace_bytes(uint64_t instance_count, uint32_t mesh_count);
+
+/* ------------------------------------------------------------------ dispatch surface
+ * Replaces the objects a caller of the reference touches to run a compute pass:
+ * vw::Shader/loadShader (/root/reference/inc/vkshader.hpp:9-37) -> kernel looked up by name;
+ * vw::ComputePipeline (/root/reference/inc/vkcompute.hpp:6-9) + vw::PipelineLayout
+ * (/root/reference/inc/vkdescriptor.hpp:58-67) -> the kernel's fixed (set,binding) slot table;
+ * vk::CommandBuffer::{bindPipeline,pushConstants,bindDescriptorSets,dispatch}
+ * (/root/reference/src/main.cpp:222-226) -> vkr_cmd_*;
+ * vw::Queue::oneTimeRecordSubmit + vw::Fence (/root/reference/inc/vkcore.hpp:34-48,140-152)
+ * -> vkr_queue_submit + vkr_fence_*.
+ *
+ * Kernel "deferred": set 0 binding 0 elements 0..3 = albedo, material, normal, depth images;
+ * set 0 binding 1 = light buffer (range / 48 = light count); set 1 binding 0 = output image;
+ * push constants [0,80) = DeferredPushData, optional [80,96) = {flags, row_offset, full_height, 0};
+ * dispatch(x, y, 1) with x, y = output extent (the reference dispatches one 1x1x1 group per pixel).
+ * Kernel "prep_indirect": set 0 bindings 0..5 = aabb_min, aabb_max, mesh_base, cmd_template,
+ * cmd_out, visible buffers, binding 6 (optional) = workspace; push constants [0,96) = planes,
+ * [96,112) = {mesh_count, first_mesh, first_instance, flags}; dispatch(instance_count, 1, 1). */
+VKR_API int32_t vkr_kernel_get(vkr_context* ctx, const char* name, vkr_kernel** out_kernel);
+VKR_API int32_t vkr_kernel_push_constant_size(vkr_kernel* kernel, uint32_t* out_min_bytes, uint32_t* out_max_bytes);
+
+VKR_API int32_t vkr_cmd_begin(vkr_context* ctx, vkr_cmd** out_cmd);
+VKR_API int32_t vkr_cmd_bind_kernel(vkr_cmd* cmd, vkr_kernel* kernel);
+/* Bytes are copied at record time, like vkCmdPushConstants.  offset+size <= 128. */
+VKR_API int32_t vkr_cmd_push_constants(vkr_cmd* cmd, uint32_t offset, uint32_t size, const void* data);
+VKR_API int32_t vkr_cmd_bind_buffer(vkr_cmd* cmd, uint32_t set, uint32_t binding, vkr_buffer* buf, uint64_t offset,
+                                    uint64_t range);
+VKR_API int32_t vkr_cmd_bind_image2d(vkr_cmd* cmd, uint32_t set, uint32_t binding, uint32_t array_element,
+                                     vkr_buffer* buf, uint64_t offset, uint32_t width, uint32_t height,
+                                     uint32_t pitch_bytes, uint32_t format);
+VKR_API int32_t vkr_cmd_dispatch(vkr_cmd* cmd, uint32_t x, uint32_t y, uint32_t z);
+VKR_API int32_t vkr_cmd_end(vkr_cmd* cmd);
+VKR_API int32_t vkr_cmd_destroy(vkr_cmd* cmd);
+
+/* Replays an ended command list on the context's stream and returns a fence that signals when it
+ * has finished.  A list may be submitted repeatedly. */
+VKR_API int32_t vkr_queue_submit(vkr_context* ctx, vkr_cmd* cmd, vkr_fence** out_fence);
+/* A fence for "everything submitted so far" (used for timing brackets). */
+VKR_API int32_t vkr_queue_marker(vkr_context* ctx, vkr_fence** out_fence);
+VKR_API int32_t vkr_queue_wait_idle(vkr_context* ctx);
+/* VKR_OK once signalled, VKR_ERR_NOT_READY otherwise (vw::Fence::signaled). */
+VKR_API int32_t vkr_fence_status(vkr_fence* fence);
+/* Blocks up to timeout_ns (UINT64_MAX = forever); VKR_ERR_NOT_READY on timeout (vw::Fence::wait). */
+VKR_API int32_t vkr_fence_wait(vkr_fence* fence, uint64_t timeout_ns);
+/* Milliseconds of GPU time between two signalled fences of one context. */
+VKR_API int32_t vkr_fence_elapsed_ms(vkr_fence* begin, vkr_fence* end, float* out_ms);
+VKR_API int32_t vkr_fence_destroy(vkr_fence* fence);
+
+/* ------------------------------------------------------------------ host math
+ * The matrices the reference's caller builds with glm before each dispatch
+ * (/root/reference/src/main.cpp:95,206-209; /root/reference/inc/vkcamera.hpp:51-53).  All 4x4
+ * matrices are column-major (m[col*4+row]), binary32. */
+VKR_API void vkr_perspective(float fovy_radians, float aspect, float z_near, float z_far, float out_m[16]);
+VKR_API void vkr_look_at(const float eye[3], const float center[3], const float up[3], float out_m[16]);
+VKR_API void vkr_mat4_mul(const float a[16], const float b[16], float out_m[16]);
+/* VKR_ERR_INVALID_ARGUMENT (out_m untouched) if the matrix is singular. */
+VKR_API int32_t vkr_mat4_inverse(const float m[16], float out_m[16]);
+/* Six un-normalised clip planes of a view-projection matrix under Vulkan clip rules
+ * (-w <= x,y <= w, 0 <= z <= w; /root/reference/shaders/offscreen.vert:31):
+ * row3+row0, row3-row0, row3+row1, row3-row1, row2, row3-row2. */
+VKR_API void vkr_frustum_planes(const float view_proj[16], float out_planes[24]);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+#endif /* VKR_C_H_ */

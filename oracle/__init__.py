@@ -1,0 +1,236 @@
+"""CPU oracle for the two hot-path passes -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import this package; the product path never does.
+
+PARITY UNPINNED: the reference has no tests/golden vectors for either pass and
+its shaders cannot be executed here (see the headers of deferred_oracle.c and
+cull_oracle.c).  The C sources restate /root/reference/shaders/deferred.comp and
+the data contract of /root/reference/src/vkmodel.cpp; this module is the ctypes
+binding plus a numpy restatement of the glm host math the reference's caller
+uses (/root/reference/src/main.cpp:95,206-209, inc/vkcamera.hpp:51-53).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile liboracle.so with gcc (see Makefile)."""
+    srcs = [os.path.join(_HERE, f) for f in ("deferred_oracle.c", "cull_oracle.c", "deferred_oracle_body.inc", "Makefile")]
+    stale = force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+class DeferredArgs(C.Structure):
+    _fields_ = [
+        ("albedo", C.c_void_p), ("material", C.c_void_p), ("normal", C.c_void_p), ("depth", C.c_void_p),
+        ("pitch_albedo", C.c_int64), ("pitch_material", C.c_int64), ("pitch_normal", C.c_int64), ("pitch_depth", C.c_int64),
+        ("width", C.c_int32), ("height", C.c_int32),
+        ("lights", C.c_void_p), ("light_count", C.c_int32),
+        ("push", C.c_void_p),
+        ("y0", C.c_int32), ("y1", C.c_int32),
+        ("flags", C.c_uint32),
+        ("out_f32", C.c_void_p), ("out_f64", C.c_void_p), ("out_rgba8", C.c_void_p), ("near_threshold", C.c_void_p),
+    ]
+
+
+class CullArgs(C.Structure):
+    _fields_ = [
+        ("aabb_min", C.c_void_p), ("aabb_max", C.c_void_p), ("instance_count", C.c_uint64),
+        ("planes", C.c_void_p), ("mesh_base", C.c_void_p), ("mesh_count", C.c_uint32),
+        ("cmd_template", C.c_void_p), ("cmd_out", C.c_void_p), ("visible", C.c_void_p), ("mask", C.c_void_p),
+    ]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        for name in ("oracle_deferred_f32", "oracle_deferred_f64", "oracle_deferred_mix"):
+            fn = getattr(_lib, name)
+            fn.argtypes = [C.POINTER(DeferredArgs)]
+            fn.restype = None
+        _lib.oracle_cull.argtypes = [C.POINTER(CullArgs)]
+        _lib.oracle_cull.restype = C.c_int
+        _lib.oracle_compute_aabb_corners.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+        _lib.oracle_compute_aabb_corners.restype = None
+        _lib.oracle_world_aabb.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.oracle_world_aabb.restype = None
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def deferred(gbuf: dict, lights: np.ndarray, push: np.ndarray, *, mode: str = "f32", rows=None,
+             radius_cutoff: bool = False, threads: int = 1, want=("f32", "rgba8")) -> dict:
+    """Evaluate the deferred resolve on the CPU.
+
+    gbuf: dict with 'albedo' (H,W,4) u8, 'material' (H,W,4) u8, 'normal' (H,W,4) f16,
+    'depth' (H,W) f32 -- arrays may be row-padded views; strides[0] is the pitch.
+    lights: (L,12) f32 (48-byte records).  push: (20,) f32 (80-byte block).
+    mode: 'f32' | 'f64' | 'mix'.  rows: (y0,y1) or None for the whole frame.
+    Returns dict with the requested outputs (full-frame arrays; only `rows` filled)
+    plus 'near_threshold'.
+    """
+    L = lib()
+    H, W = gbuf["depth"].shape
+    y0, y1 = rows if rows is not None else (0, H)
+    lights = np.ascontiguousarray(lights, dtype=np.float32).reshape(-1, 12)
+    push = np.ascontiguousarray(push, dtype=np.float32).reshape(20)
+    out = {}
+    out_f32 = np.zeros((H, W, 4), np.float32) if "f32" in want else None
+    out_f64 = np.zeros((H, W, 4), np.float64) if "f64" in want else None
+    out_u8 = np.zeros((H, W, 4), np.uint8) if "rgba8" in want else None
+    near = np.zeros((H, W), np.uint8)
+    fn = getattr(L, "oracle_deferred_" + mode)
+
+    def run(ya, yb):
+        a = DeferredArgs()
+        a.albedo, a.material = _ptr(gbuf["albedo"]), _ptr(gbuf["material"])
+        a.normal, a.depth = _ptr(gbuf["normal"]), _ptr(gbuf["depth"])
+        a.pitch_albedo, a.pitch_material = gbuf["albedo"].strides[0], gbuf["material"].strides[0]
+        a.pitch_normal, a.pitch_depth = gbuf["normal"].strides[0], gbuf["depth"].strides[0]
+        a.width, a.height = W, H
+        a.lights, a.light_count = _ptr(lights), lights.shape[0]
+        a.push = _ptr(push)
+        a.y0, a.y1 = ya, yb
+        a.flags = 1 if radius_cutoff else 0
+        a.out_f32, a.out_f64, a.out_rgba8 = _ptr(out_f32), _ptr(out_f64), _ptr(out_u8)
+        a.near_threshold = _ptr(near)
+        fn(C.byref(a))
+
+    if threads <= 1 or (y1 - y0) < 2 * threads:
+        run(y0, y1)
+    else:
+        cuts = np.linspace(y0, y1, threads * 4 + 1).astype(int)
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(lambda ab: run(int(ab[0]), int(ab[1])), zip(cuts[:-1], cuts[1:])))
+    if out_f32 is not None:
+        out["f32"] = out_f32
+    if out_f64 is not None:
+        out["f64"] = out_f64
+    if out_u8 is not None:
+        out["rgba8"] = out_u8
+    out["near_threshold"] = near
+    return out
+
+
+DRAW_CMD_DTYPE = np.dtype([("indexCount", "<u4"), ("instanceCount", "<u4"), ("firstIndex", "<u4"),
+                           ("vertexOffset", "<i4"), ("firstInstance", "<u4")])
+assert DRAW_CMD_DTYPE.itemsize == 20
+
+
+def cull(aabb_min: np.ndarray, aabb_max: np.ndarray, planes: np.ndarray, mesh_base: np.ndarray,
+         cmd_template: np.ndarray, *, want_mask: bool = True) -> dict:
+    """Sequential cull + compaction.  Returns cmds (M,) DRAW_CMD_DTYPE, visible (N,) u32
+    (slots past each mesh's count hold 0xFFFFFFFF), mask (N,) u8, bad (mesh id out of range)."""
+    L = lib()
+    aabb_min = np.ascontiguousarray(aabb_min, np.float32).reshape(-1, 4)
+    aabb_max = np.ascontiguousarray(aabb_max, np.float32).reshape(-1, 4)
+    n = aabb_min.shape[0]
+    planes = np.ascontiguousarray(planes, np.float32).reshape(6, 4)
+    mesh_base = np.ascontiguousarray(mesh_base, np.uint32)
+    m = mesh_base.shape[0]
+    cmd_template = np.ascontiguousarray(cmd_template, DRAW_CMD_DTYPE)
+    cmds = np.zeros(m, DRAW_CMD_DTYPE)
+    visible = np.full(n, 0xFFFFFFFF, np.uint32)
+    mask = np.zeros(n, np.uint8) if want_mask else None
+    a = CullArgs(_ptr(aabb_min), _ptr(aabb_max), n, _ptr(planes), _ptr(mesh_base), m,
+                 _ptr(cmd_template), _ptr(cmds), _ptr(visible), _ptr(mask))
+    bad = L.oracle_cull(C.byref(a))
+    return {"cmds": cmds, "visible": visible, "mask": mask, "bad": bool(bad)}
+
+
+def compute_aabb_corners(positions: np.ndarray) -> np.ndarray:
+    positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+    out = np.zeros((8, 3), np.float32)
+    lib().oracle_compute_aabb_corners(_ptr(positions), positions.shape[0], _ptr(out))
+    return out
+
+
+def world_aabb(corners: np.ndarray, model: np.ndarray):
+    corners = np.ascontiguousarray(corners, np.float32).reshape(8, 3)
+    model = np.ascontiguousarray(model, np.float32).reshape(16)
+    mn = np.zeros(3, np.float32)
+    mx = np.zeros(3, np.float32)
+    lib().oracle_world_aabb(_ptr(corners), _ptr(model), _ptr(mn), _ptr(mx))
+    return mn, mx
+
+
+# ---------------------------------------------------------------------------------------------
+# Host math the reference's caller takes from glm (third-party, un-vendored: the glm
+# submodule directory is empty and no version is pinned).  These restate the published
+# formulas of glm::perspective (RH, depth -1..1), glm::lookAt (RH) and a cofactor inverse,
+# all column-major (m[col*4+row]) in binary32.  They produce *inputs* to the hot path.
+# ---------------------------------------------------------------------------------------------
+
+def perspective(fovy_rad: float, aspect: float, z_near: float, z_far: float) -> np.ndarray:
+    f32 = np.float32
+    t = f32(np.tan(f32(fovy_rad) / f32(2)))
+    m = np.zeros((4, 4), np.float32)  # m[col][row]
+    m[0][0] = f32(1) / (f32(aspect) * t)
+    m[1][1] = f32(1) / t
+    m[2][2] = -(f32(z_far) + f32(z_near)) / (f32(z_far) - f32(z_near))
+    m[2][3] = -f32(1)
+    m[3][2] = -(f32(2) * f32(z_far) * f32(z_near)) / (f32(z_far) - f32(z_near))
+    return m.reshape(16)
+
+
+def look_at(eye, center, up) -> np.ndarray:
+    eye, center, up = (np.asarray(v, np.float32) for v in (eye, center, up))
+
+    def norm(v):
+        return v / np.sqrt(np.dot(v, v), dtype=np.float32)
+
+    f = norm(center - eye)
+    s = norm(np.cross(f, up).astype(np.float32))
+    u = np.cross(s, f).astype(np.float32)
+    m = np.zeros((4, 4), np.float32)
+    m[0][0], m[1][0], m[2][0] = s
+    m[0][1], m[1][1], m[2][1] = u
+    m[0][2], m[1][2], m[2][2] = -f
+    m[3][0] = -np.dot(s, eye)
+    m[3][1] = -np.dot(u, eye)
+    m[3][2] = np.dot(f, eye)
+    m[3][3] = 1
+    return m.reshape(16)
+
+
+def mat_mul(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """Column-major a*b in binary32."""
+    A = np.asarray(a, np.float32).reshape(4, 4).T  # rows x cols
+    B = np.asarray(b, np.float32).reshape(4, 4).T
+    return (A @ B).astype(np.float32).T.reshape(16)
+
+
+def inverse(m: np.ndarray) -> np.ndarray:
+    """Reference inverse in binary64, rounded to binary32 (for tolerance checks of the
+    product's fp32 cofactor inverse)."""
+    M = np.asarray(m, np.float64).reshape(4, 4).T
+    return np.linalg.inv(M).T.astype(np.float32).reshape(16)
+
+
+def frustum_planes(vp: np.ndarray) -> np.ndarray:
+    """Six un-normalised planes of a column-major view-projection for Vulkan clip rules
+    (-w<=x,y<=w, 0<=z<=w): row3+row0, row3-row0, row3+row1, row3-row1, row2, row3-row2."""
+    M = np.asarray(vp, np.float32).reshape(4, 4)  # M[col][row]
+    row = [M[:, r].copy() for r in range(4)]
+    return np.stack([row[3] + row[0], row[3] - row[0], row[3] + row[1], row[3] - row[1],
+                     row[2], row[3] - row[2]]).astype(np.float32)

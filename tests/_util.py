@@ -1,0 +1,58 @@
+"""Shared helpers for the parity tests."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+# north_star tolerance for the shaded colour: 1e-4 relative (max-abs), <= 1 LSB after the 8-bit store.
+REL_TOL = 1e-4
+# Absolute floor far below one 8-bit LSB (3.9e-3): a light whose l.n sits within rounding of the 1e-6
+# early-out threshold contributes O(1e-6) or nothing, legitimately either way.
+ABS_TOL = 2e-6
+
+
+def rel_err(got: np.ndarray, ref: np.ndarray) -> np.ndarray:
+    got = got.astype(np.float64)
+    ref = ref.astype(np.float64)
+    return np.abs(got - ref) / (np.abs(ref) + ABS_TOL / REL_TOL)
+
+
+def assert_color_close(got_rgb: np.ndarray, ref_rgb: np.ndarray, skip_mask: np.ndarray | None = None, what: str = ""):
+    """|got - ref| <= REL_TOL*|ref| + ABS_TOL on every channel of every pixel not in skip_mask."""
+    got = got_rgb.astype(np.float64)
+    ref = ref_rgb.astype(np.float64)
+    bad = np.abs(got - ref) > (REL_TOL * np.abs(ref) + ABS_TOL)
+    bad |= ~np.isfinite(got) & np.isfinite(ref)
+    if skip_mask is not None:
+        bad &= ~skip_mask.astype(bool)[..., None]
+    if bad.any():
+        idx = np.argwhere(bad)[0]
+        y, x, c = idx
+        raise AssertionError(f"{what}: {int(bad.sum())} channel(s) out of tolerance; first at (y={y},x={x},c={c}): "
+                             f"got {got[y, x, c]!r} ref {ref[y, x, c]!r} rel {abs(got[y, x, c] - ref[y, x, c]) / max(abs(ref[y, x, c]), 1e-30):.3e}")
+
+
+def run_deferred_gpu(vkr, ctx, case: dict, out_format: int, *, flags: int = 0, rows=None, pitch_pad: int = 0):
+    """Uploads a synthetic case, runs the typed entry point, returns (array, objects)."""
+    w, h = case["width"], case["height"]
+    gb = vkr.GBuffer(ctx, w, h).upload(case["gbuf"])
+    lights_np = np.ascontiguousarray(case["lights"], np.float32).reshape(-1, 12)
+    lights = ctx.buffer_from(lights_np) if lights_np.size else ctx.buffer(64)
+    out = ctx.image(out_format, w, h)
+    out.buffer.fill_u32(0)
+    r0, nr = (0, h) if rows is None else (rows[0], rows[1] - rows[0])
+    args = vkr.make_deferred_args(gb, out, lights, lights_np.shape[0], case["push"], flags=flags, row0=r0, rows=nr)
+    ctx.deferred_resolve(args)
+    ctx.wait_idle()
+    if out_format == vkr.FORMAT_R8G8B8A8_UNORM:
+        arr = out.download(np.uint8, 4)
+    elif out_format == vkr.FORMAT_R16G16B16A16_SFLOAT:
+        arr = out.download(np.float16, 4)
+    else:
+        arr = out.download(np.float32, 4)
+    return arr, (gb, lights, out)
+
+
+def sorted_segments(visible: np.ndarray, mesh_base: np.ndarray, counts: np.ndarray) -> list:
+    return [np.sort(visible[int(b):int(b) + int(c)]) for b, c in zip(mesh_base, counts)]

@@ -1,0 +1,164 @@
+"""GPU parity of the frustum cull + indirect-command compaction against the CPU oracle, through
+the C ABI.  Bar: bit-exact.  Command buffers are compared byte for byte in both modes; the
+visible-index lists are compared raw in deterministic mode and after a per-mesh sort in atomic mode
+(wave arrival order is not defined)."""
+import os
+
+import numpy as np
+import pytest
+
+from _util import sorted_segments
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _run(vkr, ctx, scene, planes, flags, **kw):
+    cs = vkr.CullScene(ctx, scene["aabb_min"], scene["aabb_max"], scene["mesh_base"], scene["cmd_template"], **kw)
+    cs.visible.fill_u32(0xFFFFFFFF)
+    cs.run(planes, flags)
+    ctx.wait_idle()
+    return cs.results(), cs
+
+
+def _compare(res, ref, scene, deterministic):
+    assert res["error"] == 0
+    assert res["cmds"].tobytes() == ref["cmds"].tobytes(), "indirect command buffer differs"
+    counts = ref["cmds"]["instanceCount"]
+    if deterministic:
+        assert np.array_equal(res["visible"], ref["visible"]), "compacted list differs (deterministic mode)"
+    else:
+        for a, b in zip(sorted_segments(res["visible"], scene["mesh_base"], counts),
+                        sorted_segments(ref["visible"], scene["mesh_base"], counts)):
+            assert np.array_equal(a, b)
+        # slots past each mesh's count were not written
+        written = np.zeros(res["visible"].shape[0], bool)
+        for b, c in zip(scene["mesh_base"], counts):
+            written[int(b):int(b) + int(c)] = True
+        assert np.all(res["visible"][~written] == 0xFFFFFFFF)
+
+
+@pytest.mark.parametrize("deterministic", [False, True])
+@pytest.mark.parametrize("n,m", [(4096, 16), (10000, 1024), (1, 1), (63, 2), (64, 1), (65, 3), (255, 7), (256, 1), (257, 300),
+                                 (1023, 5), (1024, 5), (1025, 5), (100000, 37)])
+def test_parity(vkr, synth, oracle, ctx, n, m, deterministic):
+    scene = synth.cull_case(n, m, config_index=n % 17)
+    ref = oracle.cull(scene["aabb_min"], scene["aabb_max"], scene["planes"], scene["mesh_base"], scene["cmd_template"])
+    res, _ = _run(vkr, ctx, scene, scene["planes"], vkr.CULL_DETERMINISTIC if deterministic else 0)
+    _compare(res, ref, scene, deterministic)
+
+
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_golden_fixture(vkr, ctx, deterministic):
+    z = np.load(os.path.join(GOLDEN, "cull_4096_M16.npz"))
+    scene = {k: z[k] for k in ("aabb_min", "aabb_max", "mesh_base", "cmd_template")}
+    res, _ = _run(vkr, ctx, scene, z["planes"], vkr.CULL_DETERMINISTIC if deterministic else 0)
+    _compare(res, {"cmds": z["cmds"], "visible": z["visible"]}, scene, deterministic)
+
+
+def test_adversarial_near_plane(vkr, synth, oracle, ctx):
+    """AABBs whose deciding corner is within 2 ulp of a plane: any FMA contraction or re-association on
+    the GPU flips verdicts."""
+    cam = synth.reference_camera(3840, 2160)
+    scene = synth.make_adversarial_cull(65536, synth.SEED_CULL + 99, cam, 16)
+    ref = oracle.cull(scene["aabb_min"], scene["aabb_max"], cam["planes"], scene["mesh_base"], scene["cmd_template"])
+    z = np.load(os.path.join(GOLDEN, "cull_adversarial_65536.npz"))
+    assert z["cmds"].tobytes() == ref["cmds"].tobytes()  # the oracle still reproduces its committed answer
+    frac = ref["mask"].mean()
+    assert 0.2 < frac < 0.8
+    for flags in (0, vkr.CULL_DETERMINISTIC):
+        res, _ = _run(vkr, ctx, scene, cam["planes"], flags)
+        _compare(res, ref, scene, bool(flags))
+
+
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_full_4m(vkr, synth, oracle, ctx, deterministic):
+    """BASELINE size: 2^22 instances, 1024 meshes, complete comparison with the oracle."""
+    n = 1 << 22
+    scene = synth.cull_case(n, 1024, config_index=2)
+    ref = oracle.cull(scene["aabb_min"], scene["aabb_max"], scene["planes"], scene["mesh_base"], scene["cmd_template"])
+    frac = ref["mask"].mean()
+    assert 0.05 < frac < 0.5
+    res, cs = _run(vkr, ctx, scene, scene["planes"], vkr.CULL_DETERMINISTIC if deterministic else 0)
+    _compare(res, ref, scene, deterministic)
+    assert int(res["cmds"]["instanceCount"].sum()) == int(ref["mask"].sum())
+    if not deterministic:
+        # idempotence: a second run over the same inputs gives the same commands and the same sets
+        cs.visible.fill_u32(0xFFFFFFFF)
+        cs.run(scene["planes"], 0)
+        ctx.wait_idle()
+        _compare(cs.results(), ref, scene, False)
+
+
+def test_instance_range_sharding(vkr, synth, oracle, ctx):
+    """Two calls over disjoint mesh ranges (cut at a mesh boundary) assemble into the single-call
+    result: mesh ids stay global (first_mesh), indices are global (first_instance)."""
+    n, m = 50000, 64
+    scene = synth.cull_case(n, m, config_index=5)
+    ref = oracle.cull(scene["aabb_min"], scene["aabb_max"], scene["planes"], scene["mesh_base"], scene["cmd_template"])
+    cut_mesh = 29
+    cut = int(scene["mesh_base"][cut_mesh])
+    cmds = np.zeros(m, vkr.DRAW_CMD_DTYPE)
+    visible = np.full(n, 0xFFFFFFFF, np.uint32)
+    for (m0, m1, i0, i1) in ((0, cut_mesh, 0, cut), (cut_mesh, m, cut, n)):
+        part = {"aabb_min": scene["aabb_min"][i0:i1], "aabb_max": scene["aabb_max"][i0:i1],
+                "mesh_base": scene["mesh_base"][m0:m1] - np.uint32(i0), "cmd_template": scene["cmd_template"][m0:m1]}
+        res, _ = _run(vkr, ctx, part, scene["planes"], vkr.CULL_DETERMINISTIC, first_mesh=m0, first_instance=i0)
+        assert res["error"] == 0
+        cmds[m0:m1] = res["cmds"]
+        visible[i0:i1] = res["visible"]
+    assert cmds.tobytes() == ref["cmds"].tobytes()
+    assert np.array_equal(visible, ref["visible"])
+
+
+def test_bad_mesh_id_sets_error_flag(vkr, synth, ctx):
+    scene = synth.cull_case(2000, 8, config_index=1)
+    bad = scene["aabb_min"].copy()
+    bad[:, 3] = np.full(2000, 8, np.uint32).view(np.float32)  # mesh 8 does not exist
+    scene["aabb_min"] = bad
+    # a frustum that contains everything, so the bad instances are reached
+    planes = np.zeros((6, 4), np.float32)
+    planes[:, 3] = 1.0
+    for flags in (0, vkr.CULL_DETERMINISTIC):
+        res, _ = _run(vkr, ctx, scene, planes, flags)
+        assert res["error"] == 1
+        assert int(res["cmds"]["instanceCount"].sum()) == 0
+
+
+def test_nan_box_is_culled_and_everything_visible_case(vkr, synth, oracle, ctx):
+    scene = synth.cull_case(777, 4, config_index=8)
+    scene["aabb_min"] = scene["aabb_min"].copy()
+    scene["aabb_min"][5, 0] = np.nan
+    planes = np.zeros((6, 4), np.float32)
+    planes[:, 3] = 1.0  # d = 1 >= 0 for every finite box
+    planes[0, 0] = 1e-30
+    ref = oracle.cull(scene["aabb_min"], scene["aabb_max"], planes, scene["mesh_base"], scene["cmd_template"])
+    assert int(ref["mask"].sum()) == 777 - 0  # plane 0 picks max.x (finite): the NaN min is never read
+    planes[0, 0] = -1e-30  # now the p-vertex takes min.x = NaN -> culled
+    ref = oracle.cull(scene["aabb_min"], scene["aabb_max"], planes, scene["mesh_base"], scene["cmd_template"])
+    assert int(ref["mask"].sum()) == 776
+    res, _ = _run(vkr, ctx, scene, planes, vkr.CULL_DETERMINISTIC)
+    _compare(res, ref, scene, True)
+
+
+def test_argument_errors(vkr, synth, ctx):
+    scene = synth.cull_case(100, 4)
+    cs = vkr.CullScene(ctx, scene["aabb_min"], scene["aabb_max"], scene["mesh_base"], scene["cmd_template"])
+    a = cs.args(scene["planes"], vkr.CULL_DETERMINISTIC)
+    a.workspace_bytes = 8
+    with pytest.raises(vkr.VkrError, match="workspace"):
+        ctx.prep_indirect(a)
+    a = cs.args(scene["planes"], 0)
+    a.visible = None
+    with pytest.raises(vkr.VkrError, match="null"):
+        ctx.prep_indirect(a)
+    a = cs.args(scene["planes"], 0x40)
+    with pytest.raises(vkr.VkrError, match="flags"):
+        ctx.prep_indirect(a)
+    # zero instances / zero meshes are legal no-ops
+    a = cs.args(scene["planes"], 0)
+    a.instance_count = 0
+    ctx.prep_indirect(a)
+    ctx.wait_idle()
+    assert int(cs.cmd_out.download(vkr.DRAW_CMD_DTYPE, 4)["instanceCount"].sum()) == 0

@@ -1,0 +1,170 @@
+"""GPU parity of the deferred resolve against the CPU oracle, through the C ABI.
+
+Bars (north_star): float colour within 1e-4 relative, 8-bit colour within 1 LSB.
+  * `mix` oracle  = lighting evaluated in binary64 on the reference's binary32 positions: the GPU
+                    must be within 1e-4 everywhere (pixels sitting on the 1e-6 early-out threshold
+                    are excluded: the specular term is discontinuous there).
+  * `f32` oracle  = binary32 in GLSL evaluation order: compared where that evaluation is itself
+                    well-conditioned (within 2e-5 of `mix`); its 8-bit output is compared everywhere.
+"""
+import numpy as np
+import pytest
+
+from _util import assert_color_close, rel_err, run_deferred_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracles(oracle, case, radius=False, rows=None):
+    o32 = oracle.deferred(case["gbuf"], case["lights"], case["push"], mode="f32", radius_cutoff=radius, rows=rows, threads=8)
+    omx = oracle.deferred(case["gbuf"], case["lights"], case["push"], mode="mix", radius_cutoff=radius, rows=rows, threads=8,
+                          want=("f64", "rgba8"))
+    return o32, omx
+
+
+def _check_float(got, o32, omx, what, rows=None):
+    sl = slice(None) if rows is None else slice(rows[0], rows[1])
+    g = got[sl][..., :3]
+    near = omx["near_threshold"][sl]
+    assert near.mean() < 1e-3
+    assert_color_close(g, omx["f64"][sl][..., :3], near, what + " vs mix oracle")
+    well = rel_err(o32["f32"][sl][..., :3], omx["f64"][sl][..., :3]).max(-1) <= 2e-5
+    assert well.mean() > 0.99
+    assert_color_close(g, o32["f32"][sl][..., :3], near | ~well, what + " vs f32 oracle")
+    assert np.all(got[sl][..., 3] == 1.0)
+
+
+def _check_u8(got, o32, omx, what, rows=None):
+    sl = slice(None) if rows is None else slice(rows[0], rows[1])
+    near = omx["near_threshold"][sl].astype(bool)
+    for name, ref in (("mix", omx["rgba8"]), ("f32", o32["rgba8"])):
+        d = np.abs(got[sl].astype(np.int32) - ref[sl].astype(np.int32))
+        d[near] = 0
+        assert d.max() <= 1, f"{what}: {int((d > 1).sum())} channels differ by more than 1 LSB from the {name} oracle (max {d.max()})"
+    assert np.all(got[sl][..., 3] == 255)
+
+
+@pytest.mark.parametrize("w,h,lights", [(64, 36, 13), (32, 18, 32), (32, 18, 256), (37, 19, 5), (4, 1, 1), (1, 1, 3),
+                                        (130, 33, 2), (1000, 8, 13)])
+def test_float_parity(vkr, synth, oracle, ctx, w, h, lights):
+    case = synth.deferred_case(w, h, lights, config_index=7)
+    o32, omx = _oracles(oracle, case)
+    got, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT)
+    _check_float(got, o32, omx, f"{w}x{h} L={lights}")
+
+
+@pytest.mark.parametrize("w,h,lights", [(64, 36, 13), (37, 19, 32), (128, 72, 256)])
+def test_rgba8_parity(vkr, synth, oracle, ctx, w, h, lights):
+    case = synth.deferred_case(w, h, lights, config_index=3)
+    o32, omx = _oracles(oracle, case)
+    got, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R8G8B8A8_UNORM)
+    _check_u8(got, o32, omx, f"{w}x{h} L={lights}")
+
+
+def test_rgba16f_output(vkr, synth, oracle, ctx):
+    case = synth.deferred_case(64, 36, 13, config_index=5)
+    _, omx = _oracles(oracle, case)
+    got, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R16G16B16A16_SFLOAT)
+    ref = np.clip(omx["f64"][..., :3], -65504, 65504).astype(np.float16)
+    # one half-precision ulp (the float result may sit on either side of a rounding boundary)
+    assert np.all(np.abs(got[..., :3].astype(np.float64) - ref.astype(np.float64)) <= np.spacing(np.abs(ref)).astype(np.float64))
+    assert np.all(got[..., 3] == np.float16(1.0))
+
+
+def test_zero_lights_is_ambient(vkr, synth, ctx):
+    case = synth.deferred_case(40, 10, 0)
+    got, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT)
+    amb = np.float32(0.05) * (case["gbuf"]["albedo"][..., :3].astype(np.float32) / np.float32(255))
+    np.testing.assert_allclose(got[..., :3], amb, rtol=3e-7, atol=0)
+
+
+def test_band_rows_match_full_frame(vkr, synth, ctx):
+    """Screen-band sharding: shading rows [a,b) alone gives the same bytes as the full dispatch."""
+    case = synth.deferred_case(96, 70, 32, config_index=2)
+    full, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT)
+    for rows in ((0, 9), (9, 41), (41, 70)):
+        band, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT, rows=rows)
+        assert np.array_equal(band[rows[0]:rows[1]], full[rows[0]:rows[1]])
+        rest = np.ones(70, bool)
+        rest[rows[0]:rows[1]] = False
+        assert np.all(band[rest] == 0)  # rows outside the band are untouched
+
+
+def test_radius_cutoff_extension(vkr, synth, oracle, ctx):
+    case = synth.deferred_case(64, 36, 64, config_index=4)
+    case["push"] = case["push"].copy()
+    case["push"][3] = 150.0
+    o32, omx = _oracles(oracle, case, radius=True)
+    got, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT, flags=vkr.DEFERRED_RADIUS_CUTOFF)
+    _check_float(got, o32, omx, "radius cutoff")
+    # and the cutoff really removes light: the unrestricted result is brighter somewhere
+    ref_all, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT)
+    assert (ref_all[..., :3] > got[..., :3] * 1.01).any()
+
+
+def test_golden_fixture(vkr, ctx):
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "deferred_64x36_L13.npz")
+    z = np.load(path)
+    case = {"width": 64, "height": 36, "gbuf": {k: z[k] for k in ("albedo", "material", "normal", "depth")},
+            "lights": z["lights"], "push": z["push"]}
+    got, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT)
+    assert_color_close(got[..., :3], z["out_mix_f64"][..., :3], z["near_threshold"], "golden 64x36 L13")
+    got8, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R8G8B8A8_UNORM)
+    assert np.abs(got8.astype(int) - z["out_f32_rgba8"].astype(int)).max() <= 1
+
+
+def test_full_4k_properties(vkr, synth, oracle, ctx):
+    """BASELINE size (3840x2160, 256 lights): sampled rows against the oracle plus size-independent
+    properties: linearity in the light colours and invariance to the light order."""
+    case = synth.deferred_case(3840, 2160, 256, config_index=1)
+    got, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT)
+    assert np.isfinite(got).all()
+    for rows in ((0, 2), (1079, 1081), (2158, 2160)):
+        o32, omx = _oracles(oracle, case, rows=rows)
+        _check_float(got, o32, omx, f"4K rows {rows}", rows=rows)
+    amb = 0.05 * case["gbuf"]["albedo"][..., :3].astype(np.float64) / 255.0
+    # linearity: doubling every light colour doubles (colour - ambient)
+    c2 = dict(case)
+    c2["lights"] = case["lights"].copy()
+    c2["lights"][:, 4:7] *= 2.0
+    got2, _ = run_deferred_gpu(vkr, ctx, c2, vkr.FORMAT_R32G32B32A32_SFLOAT)
+    lit1 = got[..., :3].astype(np.float64) - amb
+    lit2 = got2[..., :3].astype(np.float64) - amb
+    assert np.all(np.abs(lit2 - 2 * lit1) <= 2e-6 * np.abs(lit2) + 1e-6)
+    # permutation of the light table only changes the summation order
+    c3 = dict(case)
+    c3["lights"] = case["lights"][::-1].copy()
+    got3, _ = run_deferred_gpu(vkr, ctx, c3, vkr.FORMAT_R32G32B32A32_SFLOAT)
+    assert np.all(np.abs(got3[..., :3].astype(np.float64) - got[..., :3]) <= 2e-5 * np.abs(got[..., :3]) + 1e-6)
+    # 8-bit frame: quantisation of the float frame, within 1 LSB
+    got8, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R8G8B8A8_UNORM)
+    q = np.rint(np.clip(got[..., :3].astype(np.float64), 0, 1) * 255)
+    assert np.abs(got8[..., :3].astype(np.float64) - q).max() <= 1
+
+
+def test_argument_errors(vkr, synth, ctx):
+    case = synth.deferred_case(16, 4, 1)
+    gb = vkr.GBuffer(ctx, 16, 4).upload(case["gbuf"])
+    lights = ctx.buffer_from(case["lights"])
+    out = ctx.image(vkr.FORMAT_R8G8B8A8_UNORM, 16, 4)
+    a = vkr.make_deferred_args(gb, out, lights, 1, case["push"])
+    a.albedo.width = 15
+    with pytest.raises(vkr.VkrError, match="extent"):
+        ctx.deferred_resolve(a)
+    a = vkr.make_deferred_args(gb, out, lights, 1, case["push"])
+    a.normal.pitch_bytes = 64
+    with pytest.raises(vkr.VkrError, match="pitch"):
+        ctx.deferred_resolve(a)
+    a = vkr.make_deferred_args(gb, out, lights, 1, case["push"])
+    a.depth.format = vkr.FORMAT_R8G8B8A8_UNORM
+    with pytest.raises(vkr.VkrError, match="format"):
+        ctx.deferred_resolve(a)
+    a = vkr.make_deferred_args(gb, out, lights, 1, case["push"])
+    a.lights = None
+    with pytest.raises(vkr.VkrError, match="lights"):
+        ctx.deferred_resolve(a)
+    a = vkr.make_deferred_args(gb, out, lights, 1, case["push"])
+    a.flags = 0x80
+    with pytest.raises(vkr.VkrError, match="flags"):
+        ctx.deferred_resolve(a)

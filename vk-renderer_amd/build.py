@@ -1,0 +1,53 @@
+"""Builds libvkr_hip.so (gfx950 only) in-tree with hipcc.  No GPU is needed to build."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libvkr_hip.so")
+
+# Both kernel files are built with contraction off: the cull plane test and the deferred
+# position reconstruction must match a binary32 evaluation without fused multiply-adds; the
+# deferred light loop asks for its FMAs explicitly.
+COMMON = ["--offload-arch=gfx950", "-fPIC", "-std=c++17", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
+          "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+UNITS = [
+    ("deferred.hip", ["-O3", "-ffp-contract=off"]),
+    ("cull.hip", ["-O3", "-ffp-contract=off"]),
+    ("vkr_api.hip", ["-O2"]),
+]
+
+
+def _stale(out: str, deps: list[str]) -> bool:
+    return not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags: list[str] | None = None) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(LIB_DIR, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(ROOT, "include", "vkr_c.h")]
+    objs = []
+    for src, flags in UNITS:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s, __file__] + headers):
+            cmd = [hipcc, "-c", s, "-o", o] + COMMON + flags + (extra_flags or [])
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+    if force or _stale(LIB_PATH, objs):
+        cmd = [hipcc, "-shared", "-o", LIB_PATH, "--offload-arch=gfx950"] + objs
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,353 @@
+// Per-instance frustum cull + compaction into VkDrawIndexedIndirectCommand records for gfx950.
+// /root/reference/shaders/prep_indirect.comp:1-5 is an empty main(); the record layout and the
+// "instances of a mesh are contiguous" rule come from /root/reference/src/vkmodel.cpp:79,96,108-110
+// and /root/reference/inc/vkmodel.hpp:72,76-78.
+//
+// Compiled with -ffp-contract=off: the plane test is ((n.x*p.x + n.y*p.y) + n.z*p.z) + n.w >= 0 in
+// binary32 with separate multiplies and adds, so the visible set is bit-identical to a CPU
+// evaluation of the same expression.
+//
+// Both modes stream 32 bytes per instance (two perfectly coalesced float4 planes, 1 KiB per wave
+// instruction) and are HBM-bound.  A wave owns 256 consecutive instances (4 per lane, all eight
+// loads issued before the first use).
+//   atomic mode        : ballot -> popcount -> one atomicAdd per (wave, mesh run) on the
+//                        instanceCount field of the output command itself; lanes place their index
+//                        by mbcnt rank.  Order inside a mesh segment depends on wave arrival.
+//   deterministic mode : pass A writes one 64-bit visibility word per wave-row plus per-block
+//                        counts; pass B scans the block counts; pass C ranks the mesh boundaries
+//                        and writes the commands; pass D scatters indices in ascending order.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vkr_kernels.h"
+
+namespace {
+
+constexpr uint32_t kBlockThreads = 256;
+constexpr uint32_t kPerLane = 4;
+constexpr uint32_t kBlockInstances = kBlockThreads * kPerLane;  // 1024
+constexpr uint32_t kWordsPerBlock = kBlockInstances / 64;       // 16
+
+__device__ __forceinline__ bool aabb_visible(const float4 mn, const float4 mx, const float* __restrict__ pl) {
+  bool vis = true;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const float nx = pl[4 * k + 0], ny = pl[4 * k + 1], nz = pl[4 * k + 2], nw = pl[4 * k + 3];
+    const float px = nx >= 0.0f ? mx.x : mn.x;
+    const float py = ny >= 0.0f ? mx.y : mn.y;
+    const float pz = nz >= 0.0f ? mx.z : mn.z;
+    const float t0 = nx * px;
+    const float t1 = ny * py;
+    const float t2 = nz * pz;
+    const float d = ((t0 + t1) + t2) + nw;
+    vis = vis && (d >= 0.0f);
+  }
+  return vis;
+}
+
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ uint32_t rank_in(uint64_t mask) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+__global__ __launch_bounds__(256) void cull_init_cmds(const CullParams p) {
+  const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= p.mesh_count) return;
+  DrawCmd c = p.cmd_template[m];
+  c.instanceCount = 0u;
+  c.firstInstance = p.first_instance + p.mesh_base[m];
+  p.cmd_out[m] = c;
+}
+
+// Loads and tests the four instances of this lane.  Instance of (wave chunk, row k, lane l) is
+// chunk*256 + k*64 + l, so every wave-level load covers 1 KiB of contiguous memory.
+struct LaneWork {
+  bool vis[kPerLane];
+  uint32_t mesh[kPerLane];  // local mesh index (global id - first_mesh)
+};
+
+__device__ __forceinline__ LaneWork test_four(const CullParams& p, uint32_t chunk_base, uint32_t lane, bool& bad) {
+  float4 mn[kPerLane], mx[kPerLane];
+  bool in[kPerLane];
+#pragma unroll
+  for (uint32_t k = 0; k < kPerLane; ++k) {
+    const uint32_t i = chunk_base + k * 64u + lane;
+    in[k] = i < p.instance_count;
+    const uint32_t ic = in[k] ? i : 0u;
+    mn[k] = p.aabb_min[ic];
+    mx[k] = p.aabb_max[ic];
+  }
+  LaneWork w;
+#pragma unroll
+  for (uint32_t k = 0; k < kPerLane; ++k) {
+    w.mesh[k] = __float_as_uint(mn[k].w) - p.first_mesh;
+    bool v = in[k] && aabb_visible(mn[k], mx[k], p.planes);
+    if (v && w.mesh[k] >= p.mesh_count) {
+      bad = true;
+      v = false;
+    }
+    w.vis[k] = v;
+  }
+  return w;
+}
+
+__global__ __launch_bounds__(256) void cull_atomic_kernel(const CullParams p, uint32_t chunk_count) {
+  const uint32_t lane = lane_id();
+  const uint32_t wave = (blockIdx.x * kBlockThreads + threadIdx.x) >> 6;
+  const uint32_t wave_stride = (gridDim.x * kBlockThreads) >> 6;
+  bool bad = false;
+  for (uint32_t chunk = wave; chunk < chunk_count; chunk += wave_stride) {
+    const uint32_t chunk_base = chunk * 256u;
+    LaneWork w = test_four(p, chunk_base, lane, bad);
+    uint64_t pend[kPerLane];
+#pragma unroll
+    for (uint32_t k = 0; k < kPerLane; ++k) pend[k] = __ballot(w.vis[k]);
+    // one iteration per distinct mesh among this wave's visible instances (usually one)
+    while ((pend[0] | pend[1] | pend[2] | pend[3]) != 0ull) {
+      uint32_t m = 0;
+#pragma unroll
+      for (int k = kPerLane - 1; k >= 0; --k)
+        if (pend[k] != 0ull) m = __builtin_amdgcn_readlane(w.mesh[k], (int)__builtin_ctzll(pend[k]));
+      uint64_t same[kPerLane];
+      uint32_t total = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < kPerLane; ++k) {
+        same[k] = __ballot(w.vis[k] && w.mesh[k] == m);
+        total += (uint32_t)__popcll(same[k]);
+        pend[k] &= ~same[k];
+      }
+      uint32_t base = 0;
+      if (lane == 0u) base = atomicAdd(&p.cmd_out[m].instanceCount, total);
+      base = __builtin_amdgcn_readfirstlane(base) + p.mesh_base[m];
+#pragma unroll
+      for (uint32_t k = 0; k < kPerLane; ++k) {
+        if (w.vis[k] && w.mesh[k] == m) {
+          const uint32_t slot = base + rank_in(same[k]);
+          if (slot < p.instance_count)
+            p.visible[slot] = p.first_instance + chunk_base + k * 64u + lane;
+          else
+            bad = true;
+        }
+        base += (uint32_t)__popcll(same[k]);
+      }
+    }
+  }
+  if (bad && p.error_flag) *p.error_flag = 1u;
+}
+
+// ------------------------------------------------------------------ deterministic mode
+struct DetWorkspace {
+  uint64_t* mask;         // ceil(N/1024)*16 words
+  uint32_t* block_count;  // nblk
+  uint32_t* block_prefix; // nblk + 1
+  uint32_t* block_mesh;   // nblk + 1: local mesh index of each block's first instance; [nblk] = M-1
+  uint32_t* mesh_rank;    // M + 1
+};
+
+__host__ __device__ inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+__host__ __device__ inline DetWorkspace carve(void* base, uint64_t n, uint32_t m) {
+  const uint64_t nblk = (n + kBlockInstances - 1) / kBlockInstances;
+  uint8_t* b = static_cast<uint8_t*>(base);
+  DetWorkspace w;
+  w.mask = reinterpret_cast<uint64_t*>(b);
+  b += align_up(nblk * kWordsPerBlock * 8, 256);
+  w.block_count = reinterpret_cast<uint32_t*>(b);
+  b += align_up(nblk * 4, 256);
+  w.block_prefix = reinterpret_cast<uint32_t*>(b);
+  b += align_up((nblk + 1) * 4, 256);
+  w.block_mesh = reinterpret_cast<uint32_t*>(b);
+  b += align_up((nblk + 1) * 4, 256);
+  w.mesh_rank = reinterpret_cast<uint32_t*>(b);
+  (void)m;
+  return w;
+}
+
+// Pass A: one block per 1024 instances.
+__global__ __launch_bounds__(256) void cull_mask_kernel(const CullParams p) {
+  __shared__ uint32_t wave_count[4];
+  const DetWorkspace ws = carve(p.workspace, p.instance_count, p.mesh_count);
+  const uint32_t lane = lane_id();
+  const uint32_t wv = threadIdx.x >> 6;
+  const uint32_t blk = blockIdx.x;
+  bool bad = false;
+  // rows of this block: k*256 + wv*64 + lane  (wave wv owns words k*4 + wv)
+  float4 mn[kPerLane], mx[kPerLane];
+  bool in[kPerLane];
+#pragma unroll
+  for (uint32_t k = 0; k < kPerLane; ++k) {
+    const uint32_t i = blk * kBlockInstances + k * 256u + threadIdx.x;
+    in[k] = i < p.instance_count;
+    const uint32_t ic = in[k] ? i : 0u;
+    mn[k] = p.aabb_min[ic];
+    mx[k] = p.aabb_max[ic];
+  }
+  uint32_t cnt = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kPerLane; ++k) {
+    const uint32_t i = blk * kBlockInstances + k * 256u + threadIdx.x;
+    const uint32_t mesh = __float_as_uint(mn[k].w) - p.first_mesh;
+    bool v = in[k] && aabb_visible(mn[k], mx[k], p.planes);
+    if (in[k]) {
+      // the mesh id must agree with the segment table (deterministic mode relies on contiguity)
+      bool ok = mesh < p.mesh_count;
+      if (ok) {
+        const uint32_t lo = p.mesh_base[mesh];
+        const uint32_t hi = (mesh + 1u < p.mesh_count) ? p.mesh_base[mesh + 1u] : p.instance_count;
+        ok = (i >= lo) && (i < hi);
+      }
+      if (!ok) {
+        bad = true;
+        v = false;
+      }
+    }
+    const uint64_t word = __ballot(v);
+    if (lane == 0u) ws.mask[(uint64_t)blk * kWordsPerBlock + k * 4u + wv] = word;
+    cnt += (uint32_t)__popcll(word);
+    if (k == 0u && threadIdx.x == 0u) ws.block_mesh[blk] = in[0] ? min(mesh, p.mesh_count - 1u) : p.mesh_count - 1u;
+  }
+  if (lane == 0u) wave_count[wv] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0u) {
+    ws.block_count[blk] = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+    if (blk == gridDim.x - 1u) ws.block_mesh[gridDim.x] = p.mesh_count - 1u;
+  }
+  if (bad && p.error_flag) *p.error_flag = 1u;
+}
+
+// Pass B: exclusive scan of the block counts by one 1024-thread block.
+__global__ __launch_bounds__(1024) void cull_scan_kernel(const CullParams p, uint32_t nblk) {
+  __shared__ uint32_t wave_sum[16];
+  __shared__ uint32_t carry_s;
+  const DetWorkspace ws = carve(p.workspace, p.instance_count, p.mesh_count);
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  if (threadIdx.x == 0u) carry_s = 0u;
+  __syncthreads();
+  for (uint32_t base = 0; base < nblk; base += 1024u) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = (i < nblk) ? ws.block_count[i] : 0u;
+    // inclusive wave scan
+    uint32_t s = v;
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+      const uint32_t o = __shfl_up(s, d);
+      if (lane >= d) s += o;
+    }
+    if (lane == 63u) wave_sum[wv] = s;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (uint32_t k = 0; k < wv; ++k) woff += wave_sum[k];
+    const uint32_t carry = carry_s;
+    if (i < nblk) ws.block_prefix[i] = carry + woff + s - v;
+    __syncthreads();
+    if (threadIdx.x == 1023u) carry_s = carry + woff + s;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0u) ws.block_prefix[nblk] = carry_s;
+}
+
+// Global rank (number of visible instances with index < i).
+__device__ __forceinline__ uint32_t rank_before(const DetWorkspace& ws, uint32_t i) {
+  const uint32_t blk = i / kBlockInstances;
+  const uint32_t r = i % kBlockInstances;
+  // instance order inside a block is row-major over (k, wave, lane): word index = r / 64
+  uint32_t g = ws.block_prefix[blk];
+  const uint64_t* words = ws.mask + (uint64_t)blk * kWordsPerBlock;
+  const uint32_t w = r >> 6;
+  for (uint32_t k = 0; k < w; ++k) g += (uint32_t)__popcll(words[k]);
+  const uint32_t bit = r & 63u;
+  if (bit) g += (uint32_t)__popcll(words[w] & ((1ull << bit) - 1ull));
+  return g;
+}
+
+// Pass C: rank of every mesh boundary, then the commands.
+__global__ __launch_bounds__(256) void cull_mesh_rank_kernel(const CullParams p, uint32_t nblk) {
+  const DetWorkspace ws = carve(p.workspace, p.instance_count, p.mesh_count);
+  const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= p.mesh_count) return;
+  const uint32_t lo = p.mesh_base[m];
+  const uint32_t hi = (m + 1u < p.mesh_count) ? p.mesh_base[m + 1u] : p.instance_count;
+  const uint32_t r_lo = (lo < p.instance_count) ? rank_before(ws, lo) : ws.block_prefix[nblk];
+  const uint32_t r_hi = (hi < p.instance_count) ? rank_before(ws, hi) : ws.block_prefix[nblk];
+  ws.mesh_rank[m] = r_lo;
+  if (m == p.mesh_count - 1u) ws.mesh_rank[p.mesh_count] = r_hi;
+  DrawCmd c = p.cmd_template[m];
+  c.instanceCount = r_hi - r_lo;
+  c.firstInstance = p.first_instance + lo;
+  p.cmd_out[m] = c;
+}
+
+// Pass D: scatter.  visible[mesh_base[m] + (g - mesh_rank[m])] = i, ascending in i.
+__global__ __launch_bounds__(256) void cull_scatter_kernel(const CullParams p) {
+  __shared__ uint32_t word_prefix[kWordsPerBlock + 1];
+  __shared__ uint64_t word_s[kWordsPerBlock];
+  const DetWorkspace ws = carve(p.workspace, p.instance_count, p.mesh_count);
+  const uint32_t blk = blockIdx.x;
+  const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+  if (threadIdx.x < kWordsPerBlock) word_s[threadIdx.x] = ws.mask[(uint64_t)blk * kWordsPerBlock + threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0u) {
+    uint32_t acc = ws.block_prefix[blk];
+    for (uint32_t k = 0; k < kWordsPerBlock; ++k) {
+      word_prefix[k] = acc;
+      acc += (uint32_t)__popcll(word_s[k]);
+    }
+    word_prefix[kWordsPerBlock] = acc;
+  }
+  __syncthreads();
+  if (word_prefix[kWordsPerBlock] == word_prefix[0]) return;  // nothing visible in this block
+  const uint32_t m_first = ws.block_mesh[blk];
+  const uint32_t m_last = ws.block_mesh[blk + 1u];
+#pragma unroll
+  for (uint32_t k = 0; k < kPerLane; ++k) {
+    const uint32_t w = k * 4u + wv;
+    const uint64_t word = word_s[w];
+    if ((word >> lane) & 1ull) {
+      const uint32_t i = blk * kBlockInstances + w * 64u + lane;
+      const uint32_t g = word_prefix[w] + rank_in(word);
+      // largest m in [m_first, m_last] with mesh_base[m] <= i
+      uint32_t lo = m_first, hi = m_last;
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1u) >> 1;
+        if (p.mesh_base[mid] <= i) lo = mid; else hi = mid - 1u;
+      }
+      const uint32_t slot = p.mesh_base[lo] + (g - ws.mesh_rank[lo]);
+      if (slot < p.instance_count) p.visible[slot] = p.first_instance + i;
+    }
+  }
+}
+
+}  // namespace
+
+uint64_t vkr_cull_workspace_size(uint64_t n, uint32_t m) {
+  const uint64_t nblk = (n + kBlockInstances - 1) / kBlockInstances;
+  return align_up(nblk * kWordsPerBlock * 8, 256) + align_up(nblk * 4, 256) + 2 * align_up((nblk + 1) * 4, 256) +
+         align_up(((uint64_t)m + 1) * 4, 256);
+}
+
+hipError_t vkr_launch_cull_atomic(const CullParams& p, hipStream_t stream) {
+  if (p.mesh_count == 0u) return hipSuccess;
+  hipLaunchKernelGGL(cull_init_cmds, dim3((p.mesh_count + 255u) / 256u), dim3(256), 0, stream, p);
+  if (p.instance_count == 0u) return hipGetLastError();
+  const uint32_t chunks = (p.instance_count + 255u) / 256u;
+  // 4 waves per block; cap the grid at 8 blocks per CU and let waves stride over chunks
+  uint32_t blocks = (chunks + 3u) / 4u;
+  if (blocks > 2048u) blocks = 2048u;
+  hipLaunchKernelGGL(cull_atomic_kernel, dim3(blocks), dim3(kBlockThreads), 0, stream, p, chunks);
+  return hipGetLastError();
+}
+
+hipError_t vkr_launch_cull_deterministic(const CullParams& p, hipStream_t stream) {
+  if (p.mesh_count == 0u) return hipSuccess;
+  const uint32_t nblk = (p.instance_count + kBlockInstances - 1u) / kBlockInstances;
+  if (nblk == 0u) {
+    hipLaunchKernelGGL(cull_init_cmds, dim3((p.mesh_count + 255u) / 256u), dim3(256), 0, stream, p);
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL(cull_mask_kernel, dim3(nblk), dim3(kBlockThreads), 0, stream, p);
+  hipLaunchKernelGGL(cull_scan_kernel, dim3(1), dim3(1024), 0, stream, p, nblk);
+  hipLaunchKernelGGL(cull_mesh_rank_kernel, dim3((p.mesh_count + 255u) / 256u), dim3(256), 0, stream, p, nblk);
+  hipLaunchKernelGGL(cull_scatter_kernel, dim3(nblk), dim3(kBlockThreads), 0, stream, p);
+  return hipGetLastError();
+}

@@ -1,0 +1,299 @@
+// Deferred lighting resolve for gfx950 (MI355X): the pass of
+// /root/reference/shaders/deferred.comp:98-131, hand-written for wave64.
+//
+// This file is compiled with -ffp-contract=off: every fused multiply-add below is an explicit
+// __builtin_fmaf, so the depth -> world-position step can reproduce the reference's binary32
+// evaluation order bit for bit (it is ill-conditioned: w = a*z + b cancels as z -> 1), while the
+// per-light loop is written in a cancellation-free form that needs 4 transcendental and ~60 plain
+// VALU instructions per (pixel, light).
+//
+// Per-light algebra (unit vectors v, l, n; c = l.n; vn = v.n; H = v + l un-normalised, split into
+// its component along n, Hn = vn + c, and its tangential part Ht; HH = |H|^2 = Ht^2 + Hn^2):
+//   h.n^2            = Hn^2 / HH
+//   (a2-1) h.n^2 + 1 = (a2*Hn^2 + Ht^2) / HH            =: dn / HH      (no cancellation)
+//   D   = a2 / (PI d^2)            = a2 * HH^2 / (PI * dn^2)            (deferred.comp:59-62)
+//   v.h = l.h = sqrt(HH) / 2,  (v.h)^2 = HH / 4                          (deferred.comp:47,89)
+//   f90 = 0.5 r + 2 (l.h)^2 r      = 0.5 r + 0.5 r HH                    (deferred.comp:48-50)
+//   Lambda(c) + 1 = (c + sqrt(a2 c^2 + 1)) / (2c)                        (deferred.comp:64-70)
+//   G   = 1 / ((Lambda(vn)+1)(Lambda(c)+1))                              (deferred.comp:72-76)
+// so  specular = F * D * G * 0.25 / vn = F * [HH^2 * c / (dn^2 (c + q))] * Kspec,
+//     q = sqrt(a2 c^2 + 1),  Kspec = a2 / (PI (vn + sqrt(a2 vn^2 + 1)))  (per pixel)
+// and F = Cs + (1 - Cs) (1 - v.h)^5 splits the light sum into two colour-weighted sums.
+// The light vector is rotated into a per-pixel orthonormal frame (T, B, N) so that Ht is obtained
+// directly as (l.T + v.T, l.B + v.B) instead of as |H|^2 - Hn^2.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vkr_kernels.h"
+
+namespace {
+
+constexpr float kPi = 3.14159f;  // deferred.comp:3 (truncated on purpose)
+constexpr float kAmbient = 0.05f;
+constexpr float kAlphaFloor = 0.0064f;
+constexpr float kEarlyOut = 1e-6f;
+constexpr float kInvDistFloor = 1e7f;  // 1 / 1e-7 (deferred.comp:122)
+
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float rsq_(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float clamp01_(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
+__device__ __forceinline__ float pow5_(float t) {
+  const float t2 = t * t;
+  const float t4 = t2 * t2;
+  return t4 * t;
+}
+__device__ __forceinline__ float const_inv151() { return __uint_as_float(0x3F298953u); }  // 1.0/1.51 as folded
+
+struct Pixel {
+  // geometry
+  float px, py, pz;            // world position (bit-identical to the binary32 reference order)
+  float tx, ty, tz;            // tangent frame
+  float bx, by, bz;
+  float nx, ny, nz;            // shading normal = -normalize(gbuffer normal)
+  float vt, vb, vn;            // view direction in the frame
+  // material
+  float a2, rh, ebm1, pv;      // alpha^2, roughness/2, energyBias-1, (1-vn)^5
+  // accumulators: sum_j color_j * {diffuse, spec, spec*(1-v.h)^5} scalar weights
+  float ad[3], as0[3], as1[3];
+};
+
+// One light applied to one pixel.  lp = light position, lc = light colour (wave-uniform).
+template <bool kRadius>
+__device__ __forceinline__ void shade_light(Pixel& s, float lpx, float lpy, float lpz, float lcx, float lcy, float lcz,
+                                            float radius2) {
+  const float wx = lpx - s.px, wy = lpy - s.py, wz = lpz - s.pz;
+  const float dll = fma_(wz, wz, fma_(wy, wy, wx * wx));
+  const float lt = fma_(wz, s.tz, fma_(wy, s.ty, wx * s.tx));
+  const float lb = fma_(wz, s.bz, fma_(wy, s.by, wx * s.bx));
+  const float ln = fma_(wz, s.nz, fma_(wy, s.ny, wx * s.nx));
+  const float inv = rsq_(dll);
+  const float invd2 = fminf(inv * inv, kInvDistFloor);
+  const float c = ln * inv;
+  const float ht = fma_(lt, inv, s.vt);
+  const float hb = fma_(lb, inv, s.vb);
+  const float hn = c + s.vn;
+  const float ht2 = fma_(hb, hb, ht * ht);
+  const float hn2 = hn * hn;
+  const float hh = ht2 + hn2;
+  const float dn = fma_(s.a2, hn2, ht2);
+  // Fresnel terms
+  const float vh = 0.5f * sqrt_(hh);
+  const float pvh = pow5_(clamp01_(1.0f - vh));
+  const float f90m1 = fma_(hh, s.rh, s.ebm1);
+  const float pl = pow5_(clamp01_(1.0f - c));
+  const float kd = fma_(f90m1, pl, 1.0f) * fma_(f90m1, s.pv, 1.0f);
+  // specular geometry: HH^2 / (dn^2 (c + q)); the floor keeps culled lanes finite
+  const float q = sqrt_(fma_(s.a2, c * c, 1.0f));
+  const float den = fmaxf((dn * dn) * (c + q), 1e-36f);
+  const float ks0 = (hh * hh) * rcp_(den);
+  bool lit = c > kEarlyOut;
+  if (kRadius) lit = lit && (dll < radius2);
+  const float ci = lit ? c * invd2 : 0.0f;
+  const float wd = kd * ci;
+  const float ws = ks0 * ci;
+  const float wp = ws * pvh;
+  s.ad[0] = fma_(lcx, wd, s.ad[0]);
+  s.ad[1] = fma_(lcy, wd, s.ad[1]);
+  s.ad[2] = fma_(lcz, wd, s.ad[2]);
+  s.as0[0] = fma_(lcx, ws, s.as0[0]);
+  s.as0[1] = fma_(lcy, ws, s.as0[1]);
+  s.as0[2] = fma_(lcz, ws, s.as0[2]);
+  s.as1[0] = fma_(lcx, wp, s.as1[0]);
+  s.as1[1] = fma_(lcy, wp, s.as1[1]);
+  s.as1[2] = fma_(lcz, wp, s.as1[2]);
+}
+
+struct Material {
+  float alb[3];
+  float rough, metal;
+};
+
+// deferred.comp:99-118: everything that does not depend on the light.
+__device__ __forceinline__ void setup_pixel(Pixel& s, Material& m, const DeferredParams& p, uint32_t x, uint32_t y_full,
+                                            float depth, uint32_t albedo, uint32_t material, uint32_t nrm_lo,
+                                            uint32_t nrm_hi) {
+  // :99-103 in the reference's binary32 order (no contraction in this file)
+  const float u = ((float)x + 0.5f) / (float)p.width;
+  const float v = ((float)y_full + 0.5f) / (float)p.full_height;
+  const float cx = u * 2.0f - 1.0f;
+  const float cy = v * 2.0f - 1.0f;
+  const float* M = p.inv_vp;
+  const float wx = ((M[0] * cx + M[4] * cy) + M[8] * depth) + M[12];
+  const float wy = ((M[1] * cx + M[5] * cy) + M[9] * depth) + M[13];
+  const float wz = ((M[2] * cx + M[6] * cy) + M[10] * depth) + M[14];
+  const float ww = ((M[3] * cx + M[7] * cy) + M[11] * depth) + M[15];
+  s.px = wx / ww;
+  s.py = wy / ww;
+  s.pz = wz / ww;
+
+  const float k255 = 1.0f / 255.0f;
+  m.alb[0] = (float)(albedo & 0xFFu) * k255;
+  m.alb[1] = (float)((albedo >> 8) & 0xFFu) * k255;
+  m.alb[2] = (float)((albedo >> 16) & 0xFFu) * k255;
+  m.rough = (float)((material >> 8) & 0xFFu) * k255;
+  m.metal = (float)((material >> 16) & 0xFFu) * k255;
+
+  // :108 normal = -normalize(n)
+  const __half2 h01 = __builtin_bit_cast(__half2, nrm_lo);
+  const __half2 h23 = __builtin_bit_cast(__half2, nrm_hi);
+  const float rx = __low2float(h01), ry = __high2float(h01), rz = __low2float(h23);
+  const float rinv = -rsq_(fma_(rz, rz, fma_(ry, ry, rx * rx)));
+  s.nx = rx * rinv;
+  s.ny = ry * rinv;
+  s.nz = rz * rinv;
+
+  // orthonormal frame around N (branch-free construction)
+  const float sg = __builtin_copysignf(1.0f, s.nz);
+  const float a = -rcp_(sg + s.nz);
+  const float b = s.nx * s.ny * a;
+  s.tx = fma_(sg * s.nx, s.nx * a, 1.0f);
+  s.ty = sg * b;
+  s.tz = -sg * s.nx;
+  s.bx = b;
+  s.by = fma_(s.ny, s.ny * a, sg);
+  s.bz = -s.ny;
+
+  // :118 viewDir = normalize(cameraPos - fragPos)
+  const float ex = p.cam[0] - s.px, ey = p.cam[1] - s.py, ez = p.cam[2] - s.pz;
+  const float einv = rsq_(fma_(ez, ez, fma_(ey, ey, ex * ex)));
+  const float vx = ex * einv, vy = ey * einv, vz = ez * einv;
+  s.vt = fma_(vz, s.tz, fma_(vy, s.ty, vx * s.tx));
+  s.vb = fma_(vz, s.bz, fma_(vy, s.by, vx * s.bx));
+  s.vn = fma_(vz, s.nz, fma_(vy, s.ny, vx * s.nx));
+
+  // :116 alpha = max(r*r, 0.0064)
+  const float alpha = fmaxf(m.rough * m.rough, kAlphaFloor);
+  s.a2 = alpha * alpha;
+  s.rh = 0.5f * m.rough;
+  s.ebm1 = fma_(0.5f, m.rough, -1.0f);
+  s.pv = pow5_(clamp01_(1.0f - s.vn));
+#pragma unroll
+  for (int k = 0; k < 3; ++k) s.ad[k] = s.as0[k] = s.as1[k] = 0.0f;
+}
+
+// Combines the three light sums into the pixel colour (deferred.comp:107,114-115,127-128).
+__device__ __forceinline__ void finish_pixel(const Pixel& s, const Material& m, float out[3]) {
+  const bool front = s.vn > kEarlyOut;  // deferred.comp:43,84 (vDotN half of the early-out)
+  const float ef = fma_(const_inv151(), m.rough, 1.0f - m.rough);  // mix(1, 1/1.51, r)
+  const float kdiff = kPi * ef;
+  const float kspec = s.a2 * rcp_(kPi * (s.vn + sqrt_(fma_(s.a2, s.vn * s.vn, 1.0f))));
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float cd = m.alb[k] * (1.0f - m.metal);  // mix(albedo, 0, metal)
+    const float cs = m.alb[k] * m.metal;           // mix(0, albedo, metal)
+    const float lit = fma_(cd * kdiff, s.ad[k], kspec * fma_(cs, s.as0[k], (1.0f - cs) * s.as1[k]));
+    out[k] = fma_(kAmbient, m.alb[k], front ? lit : 0.0f);
+  }
+}
+
+__device__ __forceinline__ uint32_t quantize_unorm8(float c) {
+  // NaN -> 0, clamp, round-half-even (Vulkan float -> unorm conversion of the rgba8 store, :23,130)
+  const float t = (c > 0.0f) ? fminf(c, 1.0f) : 0.0f;
+  return (uint32_t)__builtin_rintf(t * 255.0f);
+}
+
+// Work decomposition: a 256-thread workgroup shades a 32 x 32 pixel tile; lane t owns the four
+// consecutive pixels (4*(t&7) .. +3, t>>3) of the tile, so every G-buffer plane is read with one
+// 128-bit load per lane (two for the 8-byte normals) and the 8-bit result is written with one.
+// Lights are wave-uniform: they are read through the scalar cache (s_load) straight into SGPR
+// operands, which costs no VALU issue and no VGPRs.
+template <int kOutMode, bool kRadius, int kPix>
+__global__ __launch_bounds__(256) void deferred_kernel(const DeferredParams p) {
+  const uint32_t t = threadIdx.x;
+  const uint32_t x0 = blockIdx.x * 32u + (t & 7u) * 4u;
+  const uint32_t y = blockIdx.y * 32u + (t >> 3);
+  if (x0 >= p.width || y >= p.height) return;
+  const uint32_t y_full = y + p.row_offset;
+
+  const uint4 alb4 = *reinterpret_cast<const uint4*>(p.albedo + (size_t)y * p.pitch_albedo + (size_t)x0 * 4u);
+  const uint4 mat4 = *reinterpret_cast<const uint4*>(p.material + (size_t)y * p.pitch_material + (size_t)x0 * 4u);
+  const float4 dep4 = *reinterpret_cast<const float4*>(p.depth + (size_t)y * p.pitch_depth + (size_t)x0 * 4u);
+  const uint4 nrmA = *reinterpret_cast<const uint4*>(p.normal + (size_t)y * p.pitch_normal + (size_t)x0 * 8u);
+  const uint4 nrmB = *reinterpret_cast<const uint4*>(p.normal + (size_t)y * p.pitch_normal + (size_t)x0 * 8u + 16u);
+
+  const uint32_t alb[4] = {alb4.x, alb4.y, alb4.z, alb4.w};
+  const uint32_t mat[4] = {mat4.x, mat4.y, mat4.z, mat4.w};
+  const float dep[4] = {dep4.x, dep4.y, dep4.z, dep4.w};
+  const uint32_t nlo[4] = {nrmA.x, nrmA.z, nrmB.x, nrmB.z};
+  const uint32_t nhi[4] = {nrmA.y, nrmA.w, nrmB.y, nrmB.w};
+
+  float rgb[4][3];
+  const float4* __restrict__ lights = reinterpret_cast<const float4*>(p.lights);
+  const uint32_t L = p.light_count;
+
+#pragma unroll
+  for (int g = 0; g < 4; g += kPix) {
+    Pixel s[kPix];
+    Material m[kPix];
+#pragma unroll
+    for (int i = 0; i < kPix; ++i) setup_pixel(s[i], m[i], p, x0 + g + i, y_full, dep[g + i], alb[g + i], mat[g + i], nlo[g + i], nhi[g + i]);
+
+#pragma unroll 2
+    for (uint32_t j = 0; j < L; ++j) {
+      const float4 lp = lights[3u * j];       // pos.xyz, opening_angle (unused)
+      const float4 lc = lights[3u * j + 1u];  // color.xyz, penumbra_angle (unused)
+#pragma unroll
+      for (int i = 0; i < kPix; ++i) shade_light<kRadius>(s[i], lp.x, lp.y, lp.z, lc.x, lc.y, lc.z, p.radius2);
+    }
+#pragma unroll
+    for (int i = 0; i < kPix; ++i) finish_pixel(s[i], m[i], rgb[g + i]);
+  }
+
+  const uint32_t valid = min(4u, p.width - x0);
+  uint8_t* orow = p.out + (size_t)y * p.pitch_out;
+  if (kOutMode == kOutRgba8) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      w[i] = quantize_unorm8(rgb[i][0]) | (quantize_unorm8(rgb[i][1]) << 8) | (quantize_unorm8(rgb[i][2]) << 16) | 0xFF000000u;
+    uint32_t* o = reinterpret_cast<uint32_t*>(orow) + x0;
+    if (valid == 4u) {
+      *reinterpret_cast<uint4*>(o) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        if ((uint32_t)i < valid) o[i] = w[i];
+    }
+  } else if (kOutMode == kOutRgba16f) {
+    uint2* o = reinterpret_cast<uint2*>(orow) + x0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if ((uint32_t)i < valid) {
+        const __half2 a = __floats2half2_rn(rgb[i][0], rgb[i][1]);
+        const __half2 b = __floats2half2_rn(rgb[i][2], 1.0f);
+        o[i] = make_uint2(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b));
+      }
+    }
+  } else {
+    float4* o = reinterpret_cast<float4*>(orow) + x0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if ((uint32_t)i < valid) o[i] = make_float4(rgb[i][0], rgb[i][1], rgb[i][2], 1.0f);
+  }
+}
+
+template <int kOutMode, bool kRadius>
+hipError_t launch_mode(const DeferredParams& p, hipStream_t stream) {
+  const dim3 grid((p.width + 31u) / 32u, (p.height + 31u) / 32u, 1u);
+  hipLaunchKernelGGL((deferred_kernel<kOutMode, kRadius, 2>), grid, dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t vkr_launch_deferred(const DeferredParams& p, hipStream_t stream) {
+  const bool radius = (p.flags & 1u) != 0u;
+  switch (p.out_mode) {
+    case kOutRgba8:
+      return radius ? launch_mode<kOutRgba8, true>(p, stream) : launch_mode<kOutRgba8, false>(p, stream);
+    case kOutRgba16f:
+      return radius ? launch_mode<kOutRgba16f, true>(p, stream) : launch_mode<kOutRgba16f, false>(p, stream);
+    case kOutRgba32f:
+      return radius ? launch_mode<kOutRgba32f, true>(p, stream) : launch_mode<kOutRgba32f, false>(p, stream);
+    default:
+      return hipErrorInvalidValue;
+  }
+}
