@@ -29,7 +29,7 @@ def _check_float(got, o32, omx, what, rows=None):
     assert near.mean() < 1e-3
     assert_color_close(g, omx["f64"][sl][..., :3], near, what + " vs mix oracle")
     well = rel_err(o32["f32"][sl][..., :3], omx["f64"][sl][..., :3]).max(-1) <= 2e-5
-    assert well.mean() > 0.99
+    assert well.mean() > 0.9
     assert_color_close(g, o32["f32"][sl][..., :3], near | ~well, what + " vs f32 oracle")
     assert np.all(got[sl][..., 3] == 1.0)
 
