@@ -1,0 +1,227 @@
+"""CPU-only checks: the C-ABI library loads and exports what include/vkr_c.h declares, host math,
+synthetic-input determinism, sharding helpers (including a 2-process gloo run), and the
+no-fused-multiply-add guarantee of the cull object code.  No GPU compute is called here."""
+import ctypes as C
+import hashlib
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(vkr):
+    header = open(os.path.join(ROOT, "include", "vkr_c.h")).read()
+    declared = set(re.findall(r"VKR_API\s+[\w\s\*]+?\b(vkr_\w+)\s*\(", header))
+    assert len(declared) >= 35
+    lib = vkr.lib()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in vkr_c.h but not exported"
+    assert declared == set(vkr.EXPORTS), (declared ^ set(vkr.EXPORTS))
+    nm = subprocess.run(["nm", "-D", "--defined-only", vkr.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (vkr_\w+)", nm))
+    assert declared <= exported
+    # nothing but the ABI leaks out of the shared object
+    leaked = [s for s in re.findall(r" T (\w+)", nm) if not s.startswith("vkr_") and not s.startswith("_")]
+    assert leaked == []
+
+
+def test_struct_layouts_match_the_header(vkr):
+    assert C.sizeof(vkr.Image2D) == 24
+    assert C.sizeof(vkr.DeferredArgs) == 5 * 24 + 8 + 4 + 80 + 16 + 4  # 4 bytes of padding after light_count
+    assert vkr.DeferredArgs.push.offset == 132 and vkr.DeferredArgs.row_offset.offset == 212
+    assert C.sizeof(vkr.CullArgs) == 8 + 8 + 8 + 96 + 8 + 16 + 8 * 6
+    assert vkr.DRAW_CMD_DTYPE.itemsize == 20  # VkDrawIndexedIndirectCommand
+
+
+def test_no_gpu_means_loud_failure(vkr):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(vkr.VkrError, match="no HIP device|no CPU fallback"):
+        vkr.Context(0)
+
+
+def test_host_math_matches_restated_glm(vkr, oracle):
+    fov = float(np.radians(np.float32(70.0)))
+    for aspect in (1.0, 16 / 9, 1000 / 800):
+        assert np.array_equal(vkr.perspective(fov, aspect, 0.1, 10000.0), oracle.perspective(fov, aspect, 0.1, 10000.0))
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        eye = rng.standard_normal(3).astype(np.float32) * 50
+        fwd = rng.standard_normal(3).astype(np.float32)
+        up = np.array([0, -1, 0], np.float32)
+        v = vkr.look_at(eye, eye + fwd, up)
+        np.testing.assert_allclose(v, oracle.look_at(eye, eye + fwd, up), rtol=2e-6, atol=2e-5)
+        p = vkr.perspective(fov, 1.5, 0.1, 10000.0)
+        vp = vkr.mat4_mul(p, v)
+        np.testing.assert_allclose(vp, oracle.mat_mul(p, v), rtol=1e-5, atol=1e-4)
+        inv = vkr.mat4_inverse(vp)
+        ref = oracle.inverse(vp)
+        # inv(VP)*VP = I to what a binary32 cofactor inverse gives for this badly scaled matrix (cond ~1e5..1e6)
+        prod = inv.astype(np.float64).reshape(4, 4).T @ vp.astype(np.float64).reshape(4, 4).T
+        assert np.abs(prod - np.eye(4)).max() < 5e-2
+        np.testing.assert_allclose(inv, ref, rtol=0, atol=1e-2 * np.abs(ref).max())
+        assert np.array_equal(vkr.frustum_planes(vp), oracle.frustum_planes(vp))
+    with pytest.raises(vkr.VkrError, match="singular"):
+        vkr.mat4_inverse(np.zeros(16, np.float32))
+
+
+def test_frustum_planes_classify_clip_space_points(vkr, synth):
+    cam = synth.reference_camera(1920, 1080)
+    vp = cam["vp"].astype(np.float64).reshape(4, 4).T
+    planes = cam["planes"].astype(np.float64)
+    rng = np.random.default_rng(5)
+    pts = cam["pos"].astype(np.float64) + rng.standard_normal((4000, 3)) * 300
+    clip = (vp @ np.c_[pts, np.ones(len(pts))].T).T
+    inside_clip = (np.abs(clip[:, 0]) <= clip[:, 3]) & (np.abs(clip[:, 1]) <= clip[:, 3]) & (clip[:, 2] >= 0) & (clip[:, 2] <= clip[:, 3])
+    d = pts @ planes[:, :3].T + planes[:, 3]
+    margin = np.abs(d).min(1) > 1e-3
+    assert np.array_equal(inside_clip[margin], (d >= 0).all(1)[margin])
+    assert 0.02 < inside_clip.mean() < 0.6
+
+
+def test_synth_is_deterministic(synth):
+    a = synth.deferred_case(48, 20, 7, config_index=1)
+    b = synth.deferred_case(48, 20, 7, config_index=1)
+    for k in ("albedo", "material", "normal", "depth"):
+        assert np.array_equal(a["gbuf"][k], b["gbuf"][k])
+    assert np.array_equal(a["lights"], b["lights"])
+    c = synth.deferred_case(48, 20, 7, config_index=2)
+    assert not np.array_equal(a["gbuf"]["albedo"], c["gbuf"]["albedo"])
+    # pinned stream: splitmix64 counter mode
+    assert synth.u64_stream(1, 2, 3).tolist() == synth.u64_stream(1, 2, 3).tolist()
+    digest = hashlib.sha256(synth.u64_stream(0x5EED0001, 1, 16).tobytes()).hexdigest()
+    assert digest == hashlib.sha256(synth.u64_stream(0x5EED0001, 1, 32)[:16].tobytes()).hexdigest()  # word i depends on i only
+    s = synth.cull_case(5000, 64)
+    assert s["sizes"].sum() == 5000 and s["mesh_base"][0] == 0
+    assert np.array_equal(np.repeat(np.arange(64, dtype=np.uint32), s["sizes"]), s["mesh_id"])
+    n = s["gbuf"]["normal"] if "gbuf" in s else None
+    assert n is None
+
+
+def test_synthetic_gbuffer_statistics(synth, oracle):
+    case = synth.deferred_case(160, 90, 13)
+    g = case["gbuf"]
+    assert g["depth"].min() >= 0.9 and g["depth"].max() <= 0.9995
+    assert g["albedo"][..., 3].min() == 255 and g["normal"][..., 3].min() == 1.0
+    nlen = np.linalg.norm(g["normal"][..., :3].astype(np.float64), axis=-1)
+    assert 0.45 < nlen.min() and nlen.max() < 2.05
+    # ~10 % of the pixels face away from the camera (early-out path)
+    P = synth.unproject(case["camera"]["inv_vp"], 160, 90, g["depth"])
+    V = case["camera"]["pos"].astype(np.float64) - P
+    facing = ((-g["normal"][..., :3].astype(np.float64)) * V).sum(-1) > 0
+    assert 0.85 < facing.mean() < 0.95
+    assert (g["material"][..., 1] < 21).mean() > 0.03  # roughness below the alpha floor is exercised
+
+
+def test_partition_helpers(vkr):
+    dist = __import__("importlib").import_module("vk-renderer_amd.dist")
+    for h, w in ((2160, 8), (4320, 8), (1080, 7), (5, 8), (1, 3)):
+        rows = [dist.band_rows(h, w, r) for r in range(w)]
+        assert rows[0][0] == 0 and rows[-1][1] == h
+        assert all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+        sizes = [b - a for a, b in rows]
+        assert max(sizes) - min(sizes) <= 1
+    assert list(dist.frame_slices(64, 8, 3)) == list(range(3, 64, 8))
+    base = np.array([0, 0, 10, 10, 500, 900, 1000], np.uint32)  # zero-size meshes included
+    for world in (1, 2, 3, 8):
+        cuts = dist.mesh_range_cuts(base, 1200, world)
+        assert cuts[0][0] == 0 and cuts[0][2] == 0 and cuts[-1][1] == 7 and cuts[-1][3] == 1200
+        for a, b in zip(cuts, cuts[1:]):
+            assert a[1] == b[0] and a[3] == b[2]
+        for m0, m1, i0, i1 in cuts:
+            assert m0 <= m1 and i0 <= i1
+            if m0 < m1:
+                assert i0 == base[m0]
+
+
+GLOO_WORKER = r'''
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+import torch.distributed as dist
+import oracle
+synth = importlib.import_module("vk-renderer_amd.synth")
+vdist = importlib.import_module("vk-renderer_amd.dist")
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2)
+rank = dist.get_rank()
+# screen bands: each rank shades its rows with the stand-in compute, gathered frame == single-process frame
+case = synth.deferred_case(40, 23, 5, config_index=3)
+def band(r0, r1):
+    return oracle.deferred(case["gbuf"], case["lights"], case["push"], mode="f32", rows=(r0, r1))["rgba8"][r0:r1]
+frame = vdist.sharded_deferred(23, 2, rank, band, vdist.torch_all_gather_numpy)
+full = oracle.deferred(case["gbuf"], case["lights"], case["push"], mode="f32")["rgba8"]
+assert np.array_equal(frame, full), "band gather differs"
+# instance ranges cut on mesh boundaries
+scene = synth.cull_case(3000, 37, config_index=4)
+def rng(m0, m1, i0, i1):
+    res = oracle.cull(scene["aabb_min"][i0:i1], scene["aabb_max"][i0:i1], scene["planes"], scene["mesh_base"][m0:m1] - np.uint32(i0),
+                      scene["cmd_template"][m0:m1]) if m1 > m0 else {{"cmds": np.zeros(0, oracle.DRAW_CMD_DTYPE), "visible": np.zeros(0, np.uint32)}}
+    cm, vis = res["cmds"].copy(), res["visible"].copy()
+    if m1 > m0:
+        # the oracle works on local ids/indices: globalise like first_mesh / first_instance do on the GPU
+        sub = scene["aabb_min"][i0:i1].copy()
+        sub[:, 3] = (sub[:, 3].view(np.uint32) - np.uint32(m0)).view(np.float32)
+        res = oracle.cull(sub, scene["aabb_max"][i0:i1], scene["planes"], scene["mesh_base"][m0:m1] - np.uint32(i0), scene["cmd_template"][m0:m1])
+        cm, vis = res["cmds"].copy(), res["visible"].copy()
+        cm["firstInstance"] += np.uint32(i0)
+        vis = np.where(vis == 0xFFFFFFFF, vis, vis + np.uint32(i0))
+    return cm, vis
+cmds, visible = vdist.sharded_cull(scene["mesh_base"], 3000, 2, rank, rng, vdist.torch_all_gather_numpy)
+ref = oracle.cull(scene["aabb_min"], scene["aabb_max"], scene["planes"], scene["mesh_base"], scene["cmd_template"])
+assert cmds.tobytes() == ref["cmds"].tobytes(), "sharded command buffer differs"
+assert np.array_equal(visible, ref["visible"]), "sharded visible list differs"
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_two_process_gloo_sharding(tmp_path):
+    """world_size 2 on CPU (gloo): the band gather and the mesh-range cull assembly reproduce the
+    single-process result.  The per-rank compute is the oracle standing in for the HIP entry points."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "worker.py"
+    script.write_text(GLOO_WORKER.format(root=ROOT, port=port))
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
+             for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{out}"
+        assert f"rank {r} ok" in out
+
+
+def test_cull_object_code_has_no_float_fma():
+    """The cull kernels must evaluate ((nx*px + ny*py) + nz*pz) + nw with separate multiplies and adds."""
+    obj = os.path.join(ROOT, "vk-renderer_amd", "lib", "cull.o")
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
+    if not (os.path.exists(obj) and all(os.path.exists(t) for t in tools)):
+        pytest.skip("object file or LLVM tools not present")
+    tmp = os.environ.get("TMPDIR", "/tmp")
+    fat, co = os.path.join(tmp, "vkr_cull_fat.bin"), os.path.join(tmp, "vkr_cull_gfx950.co")
+    subprocess.run([tools[0], f"--dump-section=.hip_fatbin={fat}", obj], check=True, capture_output=True)
+    subprocess.run([tools[1], "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}"],
+                   check=True, capture_output=True)
+    asm = subprocess.run([tools[2], "-d", co], capture_output=True, text=True, check=True).stdout
+    assert "cull_atomic_kernel" in asm and "cull_mask_kernel" in asm
+    assert re.search(r"v_(pk_)?mul_f32", asm) and re.search(r"v_(pk_)?add_f32", asm)
+    fused = re.findall(r"\bv_(?:fma|fmac|mad|mac|pk_fma)_(?:f32|legacy_f32|f16)\w*", asm)
+    assert fused == [], f"fused multiply-add in cull code: {set(fused)}"

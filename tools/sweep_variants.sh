@@ -1,0 +1,5 @@
+#!/bin/bash
+# Times each tuning variant of the library on the headline deferred workload.
+for f in vk-renderer_amd/lib/variants/libvkr_*.so; do
+  VKR_LIB_PATH=$PWD/$f timeout -k 10 120 python -u bench.py --steps 30 --warmup 10 --no-cull --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$f', round(d['value'],3), 'Gpix/s', round(d['roofline']['kernel_ms'],3), 'ms', round(d['roofline']['frac'],3))" || exit 1
+done

@@ -115,10 +115,11 @@ def lib():
     """Loads libvkr_hip.so; raises if the extension has not been built (there is no fallback)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise ImportError(f"{LIB_PATH} is missing: build it with `python vk-renderer_amd/build.py` "
+        path = os.environ.get("VKR_LIB_PATH", LIB_PATH)  # tuning builds only
+        if not os.path.exists(path):
+            raise ImportError(f"{path} is missing: build it with `python vk-renderer_amd/build.py` "
                               "(hipcc, gfx950). There is no CPU fallback.")
-        handle = C.CDLL(LIB_PATH)
+        handle = C.CDLL(path)
         for name, (res, args) in EXPORTS.items():
             fn = getattr(handle, name)
             fn.restype = res

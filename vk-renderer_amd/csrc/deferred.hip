@@ -4,7 +4,7 @@
 // This file is compiled with -ffp-contract=off: every fused multiply-add below is an explicit
 // __builtin_fmaf, so the depth -> world-position step can reproduce the reference's binary32
 // evaluation order bit for bit (it is ill-conditioned: w = a*z + b cancels as z -> 1), while the
-// per-light loop is written in a cancellation-free form that needs 4 transcendental and ~60 plain
+// per-light loop is written in a cancellation-free form that needs 4 transcendental and 60 plain
 // VALU instructions per (pixel, light).
 //
 // Per-light algebra (unit vectors v, l, n; c = l.n; vn = v.n; H = v + l un-normalised, split into
@@ -21,9 +21,22 @@
 // and F = Cs + (1 - Cs) (1 - v.h)^5 splits the light sum into two colour-weighted sums.
 // The light vector is rotated into a per-pixel orthonormal frame (T, B, N) so that Ht is obtained
 // directly as (l.T + v.T, l.B + v.B) instead of as |H|^2 - Hn^2.
+//
+// Instruction selection follows what the gfx950 vector unit was measured to do (4 waves per SIMD,
+// tools/ubench_valu2.hip): mul/add/fma with VGPR, inline-constant or literal operands and the
+// clamp output modifier issue every 2 cycles; anything with an SGPR operand, v_min/v_max/v_med3,
+// compares and conversions take ~3.2; a lone transcendental in a plain stream costs 13-17 cycles,
+// but four adjacent ones cost ~2.8 each.  Hence: light records are staged in LDS and read back
+// with broadcast ds_read_b128 into VGPRs (free next to VALU work) instead of being used as SGPR
+// operands; min/max/select are replaced by clamp-modifier arithmetic; and four (pixel, light)
+// pairs advance in lockstep.  A transcendental costs as much as ~8 plain instructions in this mix
+// (measured by ablation on this kernel: 2.07 ms with the 16 per iteration replaced by moves, 2.87 ms
+// with them); a degree-5 polynomial for sqrt(1 + a2 c^2) measured the same as the instruction, so
+// the instruction (1 ulp) stays.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "vkr_kernels.h"
 
@@ -33,7 +46,11 @@ constexpr float kPi = 3.14159f;  // deferred.comp:3 (truncated on purpose)
 constexpr float kAmbient = 0.05f;
 constexpr float kAlphaFloor = 0.0064f;
 constexpr float kEarlyOut = 1e-6f;
-constexpr float kInvDistFloor = 1e7f;  // 1 / 1e-7 (deferred.comp:122)
+constexpr float kDistFloor = 1e-7f;        // deferred.comp:122
+constexpr float kInvDistFloor = 1e7f;      // 1 / kDistFloor
+constexpr float kStepScale = 0x1p100f;     // (c - 1e-6) * 2^100 saturates the clamp for any c > 1e-6
+constexpr float kRadiusStepScale = 0x1p80f;
+constexpr int kChunk = 512;                // lights per LDS chunk: 2 float4 each = 16 KiB
 
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -47,6 +64,20 @@ __device__ __forceinline__ float pow5_(float t) {
 }
 __device__ __forceinline__ float const_inv151() { return __uint_as_float(0x3F298953u); }  // 1.0/1.51 as folded
 
+// Four transcendentals issued back to back (see the note on instruction selection above).  The
+// trailing s_nop covers the one wait state a transcendental result needs before a plain VALU
+// instruction may read it, which the compiler cannot see inside an asm statement.
+#define VKR_TRANS4(NAME, OP)                                                                            \
+  __device__ __forceinline__ void NAME(float (&o)[4], const float (&x)[4]) {                            \
+    asm(OP " %0, %4\n\t" OP " %1, %5\n\t" OP " %2, %6\n\t" OP " %3, %7\n\ts_nop 0"                    \
+        : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])                                            \
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));                                                  \
+  }
+VKR_TRANS4(rsq4, "v_rsq_f32")
+VKR_TRANS4(sqrt4, "v_sqrt_f32")
+VKR_TRANS4(rcp4, "v_rcp_f32")
+#undef VKR_TRANS4
+
 struct Pixel {
   // geometry
   float px, py, pz;            // world position (bit-identical to the binary32 reference order)
@@ -56,54 +87,90 @@ struct Pixel {
   float vt, vb, vn;            // view direction in the frame
   // material
   float a2, rh, ebm1, pv;      // alpha^2, roughness/2, energyBias-1, (1-vn)^5
-  // accumulators: sum_j color_j * {diffuse, spec, spec*(1-v.h)^5} scalar weights
+  // accumulators: 1e-7 * sum_j color_j * {diffuse, spec, spec*(1-v.h)^5} scalar weights
   float ad[3], as0[3], as1[3];
 };
 
-// One light applied to one pixel.  lp = light position, lc = light colour (wave-uniform).
+struct Light {
+  float px, py, pz, cx, cy, cz;
+};
+
+// Two lights applied to two pixels: the four (pixel, light) pairs k = 0..3 are (a,A) (b,A) (a,B) (b,B).
+// Every weight carries a factor 1e-7 (the distance floor is applied as clamp(inv^2 * 1e-7), which
+// equals min(1/d^2, 1e7) * 1e-7); finish_pixel() multiplies it back.
+struct LoopConsts {
+  float step_scale, step_bias, dist_floor, radius2_scaled;
+};
+
 template <bool kRadius>
-__device__ __forceinline__ void shade_light(Pixel& s, float lpx, float lpy, float lpz, float lcx, float lcy, float lcz,
-                                            float radius2) {
-  const float wx = lpx - s.px, wy = lpy - s.py, wz = lpz - s.pz;
-  const float dll = fma_(wz, wz, fma_(wy, wy, wx * wx));
-  const float lt = fma_(wz, s.tz, fma_(wy, s.ty, wx * s.tx));
-  const float lb = fma_(wz, s.bz, fma_(wy, s.by, wx * s.bx));
-  const float ln = fma_(wz, s.nz, fma_(wy, s.ny, wx * s.nx));
-  const float inv = rsq_(dll);
-  const float invd2 = fminf(inv * inv, kInvDistFloor);
-  const float c = ln * inv;
-  const float ht = fma_(lt, inv, s.vt);
-  const float hb = fma_(lb, inv, s.vb);
-  const float hn = c + s.vn;
-  const float ht2 = fma_(hb, hb, ht * ht);
-  const float hn2 = hn * hn;
-  const float hh = ht2 + hn2;
-  const float dn = fma_(s.a2, hn2, ht2);
-  // Fresnel terms
-  const float vh = 0.5f * sqrt_(hh);
-  const float pvh = pow5_(clamp01_(1.0f - vh));
-  const float f90m1 = fma_(hh, s.rh, s.ebm1);
-  const float pl = pow5_(clamp01_(1.0f - c));
-  const float kd = fma_(f90m1, pl, 1.0f) * fma_(f90m1, s.pv, 1.0f);
-  // specular geometry: HH^2 / (dn^2 (c + q)); the floor keeps culled lanes finite
-  const float q = sqrt_(fma_(s.a2, c * c, 1.0f));
-  const float den = fmaxf((dn * dn) * (c + q), 1e-36f);
-  const float ks0 = (hh * hh) * rcp_(den);
-  bool lit = c > kEarlyOut;
-  if (kRadius) lit = lit && (dll < radius2);
-  const float ci = lit ? c * invd2 : 0.0f;
-  const float wd = kd * ci;
-  const float ws = ks0 * ci;
-  const float wp = ws * pvh;
-  s.ad[0] = fma_(lcx, wd, s.ad[0]);
-  s.ad[1] = fma_(lcy, wd, s.ad[1]);
-  s.ad[2] = fma_(lcz, wd, s.ad[2]);
-  s.as0[0] = fma_(lcx, ws, s.as0[0]);
-  s.as0[1] = fma_(lcy, ws, s.as0[1]);
-  s.as0[2] = fma_(lcz, ws, s.as0[2]);
-  s.as1[0] = fma_(lcx, wp, s.as1[0]);
-  s.as1[1] = fma_(lcy, wp, s.as1[1]);
-  s.as1[2] = fma_(lcz, wp, s.as1[2]);
+__device__ __forceinline__ void shade4(Pixel& a, Pixel& b, const Light& A, const Light& B, const LoopConsts& kc) {
+  float dll[4], lt[4], lb[4], ln[4], inv[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const Pixel& s = (k & 1) ? b : a;
+    const Light& l = (k & 2) ? B : A;
+    const float wx = l.px - s.px, wy = l.py - s.py, wz = l.pz - s.pz;
+    dll[k] = fma_(wz, wz, fma_(wy, wy, wx * wx));
+    lt[k] = fma_(wz, s.tz, fma_(wy, s.ty, wx * s.tx));
+    lb[k] = fma_(wz, s.bz, fma_(wy, s.by, wx * s.bx));
+    ln[k] = fma_(wz, s.nz, fma_(wy, s.ny, wx * s.nx));
+  }
+  rsq4(inv, dll);
+  float c[4], hh[4], dn[4], att[4], sh[4], qa[4], q[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const Pixel& s = (k & 1) ? b : a;
+    c[k] = ln[k] * inv[k];
+    const float ht = fma_(lt[k], inv[k], s.vt);
+    const float hb = fma_(lb[k], inv[k], s.vb);
+    const float hn = c[k] + s.vn;
+    const float ht2 = fma_(hb, hb, ht * ht);
+    const float hn2 = hn * hn;
+    hh[k] = ht2 + hn2;
+    dn[k] = fma_(s.a2, hn2, ht2);
+    att[k] = clamp01_((inv[k] * inv[k]) * kc.dist_floor);  // min(1/d^2, 1e7) * 1e-7
+  }
+  sqrt4(sh, hh);
+  float kd[4], pvh[4], den[4], rden[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const Pixel& s = (k & 1) ? b : a;
+    pvh[k] = pow5_(clamp01_(fma_(sh[k], -0.5f, 1.0f)));  // (1 - v.h)^5
+    const float f90m1 = fma_(hh[k], s.rh, s.ebm1);
+    const float pl = pow5_(clamp01_(1.0f - c[k]));
+    kd[k] = fma_(f90m1, pl, 1.0f) * fma_(f90m1, s.pv, 1.0f);
+    qa[k] = fma_(s.a2, c[k] * c[k], 1.0f);
+  }
+  sqrt4(q, qa);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) den[k] = fma_(dn[k] * dn[k], c[k] + q[k], 1e-37f);  // +1e-37 keeps culled lanes finite
+  rcp4(rden, den);
+  float wd[4], ws[4], wp[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    // early-out of deferred.comp:43,84 as a multiplier: (c - 1e-6) * 2^100 is exact inside the FMA; its clamp
+    // is 1 for every c > 1e-6 and 0 for c <= 1e-6 or NaN
+    float ci = (c[k] * clamp01_(fma_(c[k], kc.step_scale, kc.step_bias))) * att[k];
+    if (kRadius) ci *= clamp01_(fma_(dll[k], -kRadiusStepScale, kc.radius2_scaled));  // 1 iff dist^2 < radius^2
+    const float ks0 = (hh[k] * hh[k]) * rden[k];
+    wd[k] = kd[k] * ci;
+    ws[k] = ks0 * ci;
+    wp[k] = ws[k] * pvh[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    Pixel& s = (k & 1) ? b : a;
+    const Light& l = (k & 2) ? B : A;
+    s.ad[0] = fma_(l.cx, wd[k], s.ad[0]);
+    s.ad[1] = fma_(l.cy, wd[k], s.ad[1]);
+    s.ad[2] = fma_(l.cz, wd[k], s.ad[2]);
+    s.as0[0] = fma_(l.cx, ws[k], s.as0[0]);
+    s.as0[1] = fma_(l.cy, ws[k], s.as0[1]);
+    s.as0[2] = fma_(l.cz, ws[k], s.as0[2]);
+    s.as1[0] = fma_(l.cx, wp[k], s.as1[0]);
+    s.as1[1] = fma_(l.cy, wp[k], s.as1[1]);
+    s.as1[2] = fma_(l.cz, wp[k], s.as1[2]);
+  }
 }
 
 struct Material {
@@ -178,8 +245,8 @@ __device__ __forceinline__ void setup_pixel(Pixel& s, Material& m, const Deferre
 __device__ __forceinline__ void finish_pixel(const Pixel& s, const Material& m, float out[3]) {
   const bool front = s.vn > kEarlyOut;  // deferred.comp:43,84 (vDotN half of the early-out)
   const float ef = fma_(const_inv151(), m.rough, 1.0f - m.rough);  // mix(1, 1/1.51, r)
-  const float kdiff = kPi * ef;
-  const float kspec = s.a2 * rcp_(kPi * (s.vn + sqrt_(fma_(s.a2, s.vn * s.vn, 1.0f))));
+  const float kdiff = (kPi * kInvDistFloor) * ef;  // the light sums carry a factor 1e-7
+  const float kspec = (s.a2 * kInvDistFloor) * rcp_(kPi * (s.vn + sqrt_(fma_(s.a2, s.vn * s.vn, 1.0f))));
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const float cd = m.alb[k] * (1.0f - m.metal);  // mix(albedo, 0, metal)
@@ -198,21 +265,28 @@ __device__ __forceinline__ uint32_t quantize_unorm8(float c) {
 // Work decomposition: a 256-thread workgroup shades a 32 x 32 pixel tile; lane t owns the four
 // consecutive pixels (4*(t&7) .. +3, t>>3) of the tile, so every G-buffer plane is read with one
 // 128-bit load per lane (two for the 8-byte normals) and the 8-bit result is written with one.
-// Lights are wave-uniform: they are read through the scalar cache (s_load) straight into SGPR
-// operands, which costs no VALU issue and no VGPRs.
-template <int kOutMode, bool kRadius, int kPix>
-__global__ __launch_bounds__(256) void deferred_kernel(const DeferredParams p) {
+// The lane shades its four pixels as two pairs; each pair runs the light loop two lights at a time.
+// The light table is staged through LDS in chunks of kChunk records (pos.xyz, color.xyz as two
+// float4), padded to an even count with a black light.
+// launch bound: 4 waves per SIMD (<= 128 VGPRs); measured 1-2 % faster than the 3 waves the allocator
+// settles on unprompted.
+template <int kOutMode, bool kRadius>
+__global__ __launch_bounds__(256, 4) void deferred_kernel(const DeferredParams p) {
+  __shared__ float4 s_light[2 * kChunk];
   const uint32_t t = threadIdx.x;
   const uint32_t x0 = blockIdx.x * 32u + (t & 7u) * 4u;
   const uint32_t y = blockIdx.y * 32u + (t >> 3);
-  if (x0 >= p.width || y >= p.height) return;
-  const uint32_t y_full = y + p.row_offset;
+  const bool inside = (x0 < p.width) && (y < p.height);
+  // lanes outside the image shade the tile's first group (in bounds by construction) and store nothing
+  const uint32_t lx = inside ? x0 : blockIdx.x * 32u;
+  const uint32_t ly = inside ? y : blockIdx.y * 32u;
+  const uint32_t y_full = ly + p.row_offset;
 
-  const uint4 alb4 = *reinterpret_cast<const uint4*>(p.albedo + (size_t)y * p.pitch_albedo + (size_t)x0 * 4u);
-  const uint4 mat4 = *reinterpret_cast<const uint4*>(p.material + (size_t)y * p.pitch_material + (size_t)x0 * 4u);
-  const float4 dep4 = *reinterpret_cast<const float4*>(p.depth + (size_t)y * p.pitch_depth + (size_t)x0 * 4u);
-  const uint4 nrmA = *reinterpret_cast<const uint4*>(p.normal + (size_t)y * p.pitch_normal + (size_t)x0 * 8u);
-  const uint4 nrmB = *reinterpret_cast<const uint4*>(p.normal + (size_t)y * p.pitch_normal + (size_t)x0 * 8u + 16u);
+  const uint4 alb4 = *reinterpret_cast<const uint4*>(p.albedo + (size_t)ly * p.pitch_albedo + (size_t)lx * 4u);
+  const uint4 mat4 = *reinterpret_cast<const uint4*>(p.material + (size_t)ly * p.pitch_material + (size_t)lx * 4u);
+  const float4 dep4 = *reinterpret_cast<const float4*>(p.depth + (size_t)ly * p.pitch_depth + (size_t)lx * 4u);
+  const uint4 nrmA = *reinterpret_cast<const uint4*>(p.normal + (size_t)ly * p.pitch_normal + (size_t)lx * 8u);
+  const uint4 nrmB = *reinterpret_cast<const uint4*>(p.normal + (size_t)ly * p.pitch_normal + (size_t)lx * 8u + 16u);
 
   const uint32_t alb[4] = {alb4.x, alb4.y, alb4.z, alb4.w};
   const uint32_t mat[4] = {mat4.x, mat4.y, mat4.z, mat4.w};
@@ -220,42 +294,74 @@ __global__ __launch_bounds__(256) void deferred_kernel(const DeferredParams p) {
   const uint32_t nlo[4] = {nrmA.x, nrmA.z, nrmB.x, nrmB.z};
   const uint32_t nhi[4] = {nrmA.y, nrmA.w, nrmB.y, nrmB.w};
 
-  float rgb[4][3];
   const float4* __restrict__ lights = reinterpret_cast<const float4*>(p.lights);
   const uint32_t L = p.light_count;
+  LoopConsts kc;
+  // loop constants pinned in VGPRs: as SGPR or literal operands they would halve the issue rate of their users
+  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.step_scale) : "s"(kStepScale));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.step_bias) : "s"(-kEarlyOut * kStepScale));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.dist_floor) : "s"(kDistFloor));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.radius2_scaled) : "s"(p.radius2 * kRadiusStepScale));
+  const bool wave_live = __ballot(inside) != 0ull;  // wave-uniform
+
+  uint32_t packed[4];
+  float rgb[4][3];
 
 #pragma unroll
-  for (int g = 0; g < 4; g += kPix) {
-    Pixel s[kPix];
-    Material m[kPix];
+  for (int g = 0; g < 4; g += 2) {
+    Pixel s[2];
+    Material m[2];
 #pragma unroll
-    for (int i = 0; i < kPix; ++i) setup_pixel(s[i], m[i], p, x0 + g + i, y_full, dep[g + i], alb[g + i], mat[g + i], nlo[g + i], nhi[g + i]);
+    for (int i = 0; i < 2; ++i) setup_pixel(s[i], m[i], p, lx + g + i, y_full, dep[g + i], alb[g + i], mat[g + i], nlo[g + i], nhi[g + i]);
 
-#pragma unroll 2
-    for (uint32_t j = 0; j < L; ++j) {
-      const float4 lp = lights[3u * j];       // pos.xyz, opening_angle (unused)
-      const float4 lc = lights[3u * j + 1u];  // color.xyz, penumbra_angle (unused)
-#pragma unroll
-      for (int i = 0; i < kPix; ++i) shade_light<kRadius>(s[i], lp.x, lp.y, lp.z, lc.x, lc.y, lc.z, p.radius2);
+    for (uint32_t base = 0; base < L; base += kChunk) {
+      const uint32_t n = min((uint32_t)kChunk, L - base);
+      const uint32_t n2 = (n + 1u) & ~1u;
+      __syncthreads();  // previous chunk fully consumed
+      for (uint32_t i = t; i < n2; i += 256u) {
+        float4 lp = make_float4(0.0f, 0.0f, 1e18f, 0.0f), lc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (i < n) {
+          lp = lights[3u * (base + i)];       // pos.xyz, opening_angle (unused)
+          lc = lights[3u * (base + i) + 1u];  // color.xyz, penumbra_angle (unused)
+        }
+        s_light[2u * i] = lp;
+        s_light[2u * i + 1u] = lc;
+      }
+      __syncthreads();
+      if (wave_live) {
+        float4 pa = s_light[0], ca = s_light[1], pb = s_light[2], cb = s_light[3];
+        for (uint32_t j = 0; j < n2; j += 2u) {
+          const Light A{pa.x, pa.y, pa.z, ca.x, ca.y, ca.z};
+          const Light B{pb.x, pb.y, pb.z, cb.x, cb.y, cb.z};
+          const uint32_t jn = min(j + 2u, n2 - 2u);  // last iteration re-reads its own pair
+          pa = s_light[2u * jn];
+          ca = s_light[2u * jn + 1u];
+          pb = s_light[2u * jn + 2u];
+          cb = s_light[2u * jn + 3u];
+          shade4<kRadius>(s[0], s[1], A, B, kc);
+        }
+      }
     }
 #pragma unroll
-    for (int i = 0; i < kPix; ++i) finish_pixel(s[i], m[i], rgb[g + i]);
+    for (int i = 0; i < 2; ++i) {
+      finish_pixel(s[i], m[i], rgb[g + i]);
+      if (kOutMode == kOutRgba8)
+        packed[g + i] = quantize_unorm8(rgb[g + i][0]) | (quantize_unorm8(rgb[g + i][1]) << 8) |
+                        (quantize_unorm8(rgb[g + i][2]) << 16) | 0xFF000000u;
+    }
   }
+  if (!inside) return;
 
   const uint32_t valid = min(4u, p.width - x0);
   uint8_t* orow = p.out + (size_t)y * p.pitch_out;
   if (kOutMode == kOutRgba8) {
-    uint32_t w[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      w[i] = quantize_unorm8(rgb[i][0]) | (quantize_unorm8(rgb[i][1]) << 8) | (quantize_unorm8(rgb[i][2]) << 16) | 0xFF000000u;
     uint32_t* o = reinterpret_cast<uint32_t*>(orow) + x0;
     if (valid == 4u) {
-      *reinterpret_cast<uint4*>(o) = make_uint4(w[0], w[1], w[2], w[3]);
+      *reinterpret_cast<uint4*>(o) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
     } else {
 #pragma unroll
       for (int i = 0; i < 3; ++i)
-        if ((uint32_t)i < valid) o[i] = w[i];
+        if ((uint32_t)i < valid) o[i] = packed[i];
     }
   } else if (kOutMode == kOutRgba16f) {
     uint2* o = reinterpret_cast<uint2*>(orow) + x0;
@@ -278,7 +384,7 @@ __global__ __launch_bounds__(256) void deferred_kernel(const DeferredParams p) {
 template <int kOutMode, bool kRadius>
 hipError_t launch_mode(const DeferredParams& p, hipStream_t stream) {
   const dim3 grid((p.width + 31u) / 32u, (p.height + 31u) / 32u, 1u);
-  hipLaunchKernelGGL((deferred_kernel<kOutMode, kRadius, 2>), grid, dim3(256), 0, stream, p);
+  hipLaunchKernelGGL((deferred_kernel<kOutMode, kRadius>), grid, dim3(256), 0, stream, p);
   return hipGetLastError();
 }
 
