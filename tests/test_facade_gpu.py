@@ -1,0 +1,164 @@
+"""The C++ facade (include/vkr/vkr.hpp) driven by a host program shaped like the reference's main.cpp,
+and the command-list ABI underneath it (vkr_cmd_* / vkr_queue_submit / vkr_fence_*)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tests", "cpp", "facade_frame")
+
+
+def test_cpp_facade_frame_loop(vkr, synth, oracle, tmp_path):
+    assert os.path.exists(BIN), "tests/cpp/facade_frame is built by __graft_entry__.build()"
+    w, h, L, n, m = 100, 37, 13, 6000, 40
+    case = synth.deferred_case(w, h, L, config_index=6)
+    scene = synth.cull_case(n, m, config_index=6)
+    d = str(tmp_path)
+    np.array([w, h, 5, n, m, vkr.CULL_DETERMINISTIC], np.uint32).tofile(os.path.join(d, "meta.bin"))
+    for k in ("albedo", "material", "normal", "depth"):
+        np.ascontiguousarray(case["gbuf"][k]).tofile(os.path.join(d, k + ".bin"))
+    case["lights"].tofile(os.path.join(d, "lights.bin"))
+    case["push"].tofile(os.path.join(d, "push.bin"))
+    for k in ("aabb_min", "aabb_max", "mesh_base", "cmd_template"):
+        np.ascontiguousarray(scene[k]).tofile(os.path.join(d, k + ".bin"))
+    np.ascontiguousarray(scene["planes"], np.float32).tofile(os.path.join(d, "planes.bin"))
+    r = subprocess.run([BIN, d], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "facade ok" in r.stdout and "frames=5" in r.stdout
+    ref = oracle.deferred(case["gbuf"], case["lights"], case["push"], mode="f32")
+    outs = [np.fromfile(os.path.join(d, f"out{i}.bin"), np.uint8).reshape(h, w, 4) for i in range(3)]
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert np.abs(outs[0].astype(int) - ref["rgba8"].astype(int)).max() <= 1
+    cref = oracle.cull(scene["aabb_min"], scene["aabb_max"], scene["planes"], scene["mesh_base"], scene["cmd_template"])
+    cmds = np.fromfile(os.path.join(d, "cmds.bin"), vkr.DRAW_CMD_DTYPE)
+    vis = np.fromfile(os.path.join(d, "visible.bin"), np.uint32)
+    assert cmds.tobytes() == cref["cmds"].tobytes()
+    counts = cref["cmds"]["instanceCount"]
+    for b, c in zip(scene["mesh_base"], counts):
+        assert np.array_equal(vis[int(b):int(b) + int(c)], cref["visible"][int(b):int(b) + int(c)])
+
+
+def _cmd_deferred(vkr, ctx, gb, lights, nlights, out, push, ext=None):
+    lib = vkr.lib()
+    k, cmd = C.c_void_p(), C.c_void_p()
+    vkr._check(lib.vkr_kernel_get(ctx.handle, b"deferred", C.byref(k)))
+    vkr._check(lib.vkr_cmd_begin(ctx.handle, C.byref(cmd)))
+    vkr._check(lib.vkr_cmd_bind_kernel(cmd, k))
+    data = np.ascontiguousarray(push, np.float32)
+    vkr._check(lib.vkr_cmd_push_constants(cmd, 0, 80, data.ctypes.data_as(C.c_void_p)))
+    if ext is not None:
+        e = np.asarray(ext, np.uint32)
+        vkr._check(lib.vkr_cmd_push_constants(cmd, 80, 16, e.ctypes.data_as(C.c_void_p)))
+    for i, im in enumerate((gb.albedo, gb.material, gb.normal, gb.depth)):
+        vkr._check(lib.vkr_cmd_bind_image2d(cmd, 0, 0, i, im.buffer.handle, 0, im.width, im.height, im.pitch, im.format))
+    vkr._check(lib.vkr_cmd_bind_buffer(cmd, 0, 1, lights.handle, 0, nlights * 48))
+    vkr._check(lib.vkr_cmd_bind_image2d(cmd, 1, 0, 0, out.buffer.handle, 0, out.width, out.height, out.pitch, out.format))
+    return cmd
+
+
+def test_command_list_matches_typed_entry_point(vkr, synth, ctx):
+    lib = vkr.lib()
+    case = synth.deferred_case(64, 20, 9, config_index=9)
+    gb = vkr.GBuffer(ctx, 64, 20).upload(case["gbuf"])
+    lights = ctx.buffer_from(case["lights"])
+    out_a = ctx.image(vkr.FORMAT_R32G32B32A32_SFLOAT, 64, 20)
+    out_b = ctx.image(vkr.FORMAT_R32G32B32A32_SFLOAT, 64, 20)
+    ctx.deferred_resolve(vkr.make_deferred_args(gb, out_a, lights, 9, case["push"]))
+    cmd = _cmd_deferred(vkr, ctx, gb, lights, 9, out_b, case["push"])
+    vkr._check(lib.vkr_cmd_dispatch(cmd, 64, 20, 1))
+    # recording errors: submit before end, dispatch after end
+    f = C.c_void_p()
+    assert lib.vkr_queue_submit(ctx.handle, cmd, C.byref(f)) == vkr.ERR_BAD_STATE
+    vkr._check(lib.vkr_cmd_end(cmd))
+    assert lib.vkr_cmd_dispatch(cmd, 64, 20, 1) == vkr.ERR_BAD_STATE
+    begin = ctx.marker()
+    vkr._check(lib.vkr_queue_submit(ctx.handle, cmd, C.byref(f)))
+    fence = vkr.Fence(f)
+    assert fence.wait() and fence.signaled()
+    assert fence.elapsed_ms_since(begin) >= 0.0
+    assert np.array_equal(out_a.download(np.float32, 4), out_b.download(np.float32, 4))
+    # a list can be replayed
+    out_b.buffer.fill_u32(0)
+    f2 = C.c_void_p()
+    vkr._check(lib.vkr_queue_submit(ctx.handle, cmd, C.byref(f2)))
+    vkr.Fence(f2).wait()
+    assert np.array_equal(out_a.download(np.float32, 4), out_b.download(np.float32, 4))
+    lib.vkr_cmd_destroy(cmd)
+
+
+def test_command_list_validation(vkr, synth, ctx):
+    lib = vkr.lib()
+    case = synth.deferred_case(32, 8, 2)
+    gb = vkr.GBuffer(ctx, 32, 8).upload(case["gbuf"])
+    lights = ctx.buffer_from(case["lights"])
+    out = ctx.image(vkr.FORMAT_R8G8B8A8_UNORM, 32, 8)
+    k = C.c_void_p()
+    assert lib.vkr_kernel_get(ctx.handle, b"offscreen", C.byref(k)) == vkr.ERR_NOT_FOUND
+    assert b"no kernel named" in lib.vkr_last_error()
+    # dispatch extent must equal the output extent (the reference dispatches one 1x1x1 group per pixel)
+    cmd = _cmd_deferred(vkr, ctx, gb, lights, 2, out, case["push"])
+    vkr._check(lib.vkr_cmd_dispatch(cmd, 31, 8, 1))
+    vkr._check(lib.vkr_cmd_end(cmd))
+    f = C.c_void_p()
+    assert lib.vkr_queue_submit(ctx.handle, cmd, C.byref(f)) == vkr.ERR_INVALID_ARGUMENT
+    assert b"output extent" in lib.vkr_last_error()
+    lib.vkr_cmd_destroy(cmd)
+    # missing push constants
+    cmd = C.c_void_p()
+    vkr._check(lib.vkr_kernel_get(ctx.handle, b"deferred", C.byref(k)))
+    vkr._check(lib.vkr_cmd_begin(ctx.handle, C.byref(cmd)))
+    vkr._check(lib.vkr_cmd_bind_kernel(cmd, k))
+    vkr._check(lib.vkr_cmd_dispatch(cmd, 32, 8, 1))
+    vkr._check(lib.vkr_cmd_end(cmd))
+    assert lib.vkr_queue_submit(ctx.handle, cmd, C.byref(f)) == vkr.ERR_BAD_STATE
+    lib.vkr_cmd_destroy(cmd)
+    # light buffer range must be a multiple of 48; push constants limited to 128 bytes
+    cmd = _cmd_deferred(vkr, ctx, gb, lights, 2, out, case["push"])
+    vkr._check(lib.vkr_cmd_bind_buffer(cmd, 0, 1, lights.handle, 0, 50))
+    vkr._check(lib.vkr_cmd_dispatch(cmd, 32, 8, 1))
+    vkr._check(lib.vkr_cmd_end(cmd))
+    assert lib.vkr_queue_submit(ctx.handle, cmd, C.byref(f)) == vkr.ERR_INVALID_ARGUMENT
+    z = np.zeros(64, np.uint8)
+    assert lib.vkr_cmd_push_constants(cmd, 100, 64, z.ctypes.data_as(C.c_void_p)) == vkr.ERR_BAD_STATE  # ended
+    lib.vkr_cmd_destroy(cmd)
+    ctx.wait_idle()
+
+
+def test_band_push_extension_and_host_visible_buffer(vkr, synth, ctx):
+    """Push constants [80,96) = {flags,row_offset,full_height,0} shade one band; the light table lives in a
+    persistently mapped buffer (the reference's CPU_TO_GPU UBO, src/main.cpp:109,202)."""
+    lib = vkr.lib()
+    case = synth.deferred_case(48, 30, 6, config_index=12)
+    gb = vkr.GBuffer(ctx, 48, 30).upload(case["gbuf"])
+    ubo = ctx.buffer(6 * 48, vkr.BUFFER_HOST_VISIBLE)
+    ubo.mapped()[:] = np.ascontiguousarray(case["lights"]).view(np.uint8).reshape(-1)
+    full = ctx.image(vkr.FORMAT_R8G8B8A8_UNORM, 48, 30)
+    ctx.deferred_resolve(vkr.make_deferred_args(gb, full, ubo, 6, case["push"]))
+    ctx.wait_idle()
+    want = full.download(np.uint8, 4)
+    band = ctx.image(vkr.FORMAT_R8G8B8A8_UNORM, 48, 11)
+    # band images: rows 7..18 of every plane
+    k, cmd = C.c_void_p(), C.c_void_p()
+    vkr._check(lib.vkr_kernel_get(ctx.handle, b"deferred", C.byref(k)))
+    vkr._check(lib.vkr_cmd_begin(ctx.handle, C.byref(cmd)))
+    vkr._check(lib.vkr_cmd_bind_kernel(cmd, k))
+    push = np.ascontiguousarray(case["push"], np.float32)
+    vkr._check(lib.vkr_cmd_push_constants(cmd, 0, 80, push.ctypes.data_as(C.c_void_p)))
+    ext = np.array([0, 7, 30, 0], np.uint32)
+    vkr._check(lib.vkr_cmd_push_constants(cmd, 80, 16, ext.ctypes.data_as(C.c_void_p)))
+    for i, im in enumerate((gb.albedo, gb.material, gb.normal, gb.depth)):
+        vkr._check(lib.vkr_cmd_bind_image2d(cmd, 0, 0, i, im.buffer.handle, 7 * im.pitch, 48, 11, im.pitch, im.format))
+    vkr._check(lib.vkr_cmd_bind_buffer(cmd, 0, 1, ubo.handle, 0, 6 * 48))
+    vkr._check(lib.vkr_cmd_bind_image2d(cmd, 1, 0, 0, band.buffer.handle, 0, 48, 11, band.pitch, band.format))
+    vkr._check(lib.vkr_cmd_dispatch(cmd, 48, 11, 1))
+    vkr._check(lib.vkr_cmd_end(cmd))
+    f = C.c_void_p()
+    vkr._check(lib.vkr_queue_submit(ctx.handle, cmd, C.byref(f)))
+    vkr.Fence(f).wait()
+    assert np.array_equal(band.download(np.uint8, 4), want[7:18])
+    lib.vkr_cmd_destroy(cmd)
