@@ -109,6 +109,8 @@ typedef struct vkr_image2d {
 #define VKR_DEFERRED_RADIUS_CUTOFF 1u /* extension: a light contributes only where dist^2 < pointLightRadius^2
                                          (push[3]); enables per-tile light lists.  Off = reference behaviour
                                          (pointLightRadius is pushed but never read, deferred.comp:8,120-129). */
+#define VKR_DEFERRED_NO_TILE_LISTS 2u /* with RADIUS_CUTOFF: apply the cutoff per pixel only and loop over the whole
+                                         light table (diagnostic; results are bit-identical to the tiled path) */
 
 /* One dispatch of /root/reference/shaders/deferred.comp (main, :98-131) as recorded at
  * /root/reference/src/main.cpp:222-226.  Bindings follow main.cpp:163-167,190-196:

@@ -90,16 +90,43 @@ def test_band_rows_match_full_frame(vkr, synth, ctx):
         assert np.all(band[rest] == 0)  # rows outside the band are untouched
 
 
-def test_radius_cutoff_extension(vkr, synth, oracle, ctx):
-    case = synth.deferred_case(64, 36, 64, config_index=4)
+@pytest.mark.parametrize("w,h,lights,radius", [(64, 36, 64, 150.0), (96, 40, 700, 60.0), (70, 33, 1500, 1e6), (33, 70, 300, 5.0)])
+def test_radius_cutoff_extension(vkr, synth, oracle, ctx, w, h, lights, radius):
+    """Opt-in extension (not in the reference): a light contributes only where dist^2 < radius^2.  The kernel
+    builds per-tile light lists in LDS; the result must equal the per-pixel rule of the oracle, and must be
+    bit-identical to the same kernel looping over the whole table (lists are conservative and ordered)."""
+    case = synth.deferred_case(w, h, lights, config_index=4)
     case["push"] = case["push"].copy()
-    case["push"][3] = 150.0
+    case["push"][3] = radius
     o32, omx = _oracles(oracle, case, radius=True)
     got, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT, flags=vkr.DEFERRED_RADIUS_CUTOFF)
     _check_float(got, o32, omx, "radius cutoff")
-    # and the cutoff really removes light: the unrestricted result is brighter somewhere
-    ref_all, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT)
-    assert (ref_all[..., :3] > got[..., :3] * 1.01).any()
+    flat, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT,
+                               flags=vkr.DEFERRED_RADIUS_CUTOFF | vkr.DEFERRED_NO_TILE_LISTS)
+    assert np.array_equal(got, flat)
+    if radius < 1e5:
+        # the cutoff really removes light: the unrestricted result is brighter somewhere
+        ref_all, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT)
+        assert (ref_all[..., :3] > got[..., :3] * 1.01).any()
+    else:
+        ref_all, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT)
+        assert np.array_equal(ref_all, got)  # a radius beyond every light changes nothing
+
+
+def test_radius_argument_range(vkr, synth, ctx):
+    case = synth.deferred_case(16, 4, 1)
+    gb = vkr.GBuffer(ctx, 16, 4).upload(case["gbuf"])
+    lights = ctx.buffer_from(case["lights"])
+    out = ctx.image(vkr.FORMAT_R8G8B8A8_UNORM, 16, 4)
+    for bad in (0.0, -1.0, 1e9, float("nan")):
+        push = case["push"].copy()
+        push[3] = bad
+        with pytest.raises(vkr.VkrError, match="pointLightRadius"):
+            ctx.deferred_resolve(vkr.make_deferred_args(gb, out, lights, 1, push, flags=vkr.DEFERRED_RADIUS_CUTOFF))
+    push = case["push"].copy()
+    push[3] = float("inf")
+    ctx.deferred_resolve(vkr.make_deferred_args(gb, out, lights, 1, push, flags=vkr.DEFERRED_RADIUS_CUTOFF))
+    ctx.wait_idle()
 
 
 def test_golden_fixture(vkr, ctx):

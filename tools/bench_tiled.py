@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Times the radius-cutoff extension with per-tile LDS light lists against the same cutoff applied per
+pixel over the whole table (BASELINE config: 7680x4320, 4096 lights; one GPU does the whole frame here).
+
+    python tools/bench_tiled.py [--width W --height H --lights L --radius R --steps K]
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=7680)
+    ap.add_argument("--height", type=int, default=4320)
+    ap.add_argument("--lights", type=int, default=4096)
+    ap.add_argument("--radius", type=float, default=25.0)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--flat", action="store_true", help="also time the untiled loop (slow: every light on every pixel)")
+    a = ap.parse_args()
+    vkr = importlib.import_module("vk-renderer_amd")
+    synth = importlib.import_module("vk-renderer_amd.synth")
+    ctx = vkr.Context(0)
+    case = synth.deferred_case(a.width, a.height, a.lights, config_index=3)
+    push = case["push"].copy()
+    push[3] = a.radius
+    gb = vkr.GBuffer(ctx, a.width, a.height).upload(case["gbuf"])
+    lights = ctx.buffer_from(case["lights"])
+    out = ctx.image(vkr.FORMAT_R8G8B8A8_UNORM, a.width, a.height)
+    res = {"width": a.width, "height": a.height, "lights": a.lights, "radius": a.radius}
+    modes = [("tiled", vkr.DEFERRED_RADIUS_CUTOFF)]
+    if a.flat:
+        modes.append(("per_pixel_cutoff_whole_table", vkr.DEFERRED_RADIUS_CUTOFF | vkr.DEFERRED_NO_TILE_LISTS))
+    outs = {}
+    for name, flags in modes:
+        args = vkr.make_deferred_args(gb, out, lights, a.lights, push, flags=flags)
+        ctx.deferred_resolve(args)
+        ctx.wait_idle()
+        e0 = ctx.marker()
+        for _ in range(a.steps):
+            ctx.deferred_resolve(args)
+        e1 = ctx.marker()
+        ctx.wait_idle()
+        ms = e1.elapsed_ms_since(e0) / a.steps
+        res[name] = {"ms": ms, "Gpixel_per_s": a.width * a.height / ms / 1e6, "hbm_GBps": a.width * a.height * 24 / ms / 1e6}
+        outs[name] = out.download(np.uint8, 4)
+    if len(outs) == 2:
+        res["identical"] = bool(np.array_equal(outs["tiled"], outs["per_pixel_cutoff_whole_table"]))
+    # mean number of lights within the radius per pixel, from a sample of pixels (host, float64)
+    P = synth.unproject(case["camera"]["inv_vp"], a.width, a.height, case["gbuf"]["depth"])[::97, ::89].reshape(-1, 3)
+    lp = case["lights"][:, :3].astype(np.float64)
+    d2 = ((P[:, None, :] - lp[None, :, :]) ** 2).sum(-1)
+    res["mean_lights_in_radius_per_pixel"] = float((d2 < a.radius ** 2).sum(1).mean())
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -28,6 +28,7 @@ FORMAT_R32G32B32A32_SFLOAT = 109
 FORMAT_D32_SFLOAT = 126
 BUFFER_DEVICE, BUFFER_HOST_VISIBLE = 0, 1
 DEFERRED_RADIUS_CUTOFF = 1
+DEFERRED_NO_TILE_LISTS = 2
 CULL_DETERMINISTIC = 1
 LIGHT_STRIDE = 48
 

@@ -155,6 +155,7 @@ struct DetWorkspace {
   uint32_t* block_prefix; // nblk + 1
   uint32_t* block_mesh;   // nblk + 1: local mesh index of each block's first instance; [nblk] = M-1
   uint32_t* mesh_rank;    // M + 1
+  uint16_t* word_prefix;  // nblk * 16: visible instances of the block before each 64-instance word
 };
 
 __host__ __device__ inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
@@ -172,13 +173,14 @@ __host__ __device__ inline DetWorkspace carve(void* base, uint64_t n, uint32_t m
   w.block_mesh = reinterpret_cast<uint32_t*>(b);
   b += align_up((nblk + 1) * 4, 256);
   w.mesh_rank = reinterpret_cast<uint32_t*>(b);
-  (void)m;
+  b += align_up(((uint64_t)m + 1) * 4, 256);
+  w.word_prefix = reinterpret_cast<uint16_t*>(b);
   return w;
 }
 
 // Pass A: one block per 1024 instances.
 __global__ __launch_bounds__(256) void cull_mask_kernel(const CullParams p) {
-  __shared__ uint32_t wave_count[4];
+  __shared__ uint32_t word_count[kWordsPerBlock];
   const DetWorkspace ws = carve(p.workspace, p.instance_count, p.mesh_count);
   const uint32_t lane = lane_id();
   const uint32_t wv = threadIdx.x >> 6;
@@ -195,7 +197,6 @@ __global__ __launch_bounds__(256) void cull_mask_kernel(const CullParams p) {
     mn[k] = load_stream(p.aabb_min + ic);
     mx[k] = load_stream(p.aabb_max + ic);
   }
-  uint32_t cnt = 0;
 #pragma unroll
   for (uint32_t k = 0; k < kPerLane; ++k) {
     const uint32_t i = blk * kBlockInstances + k * 256u + threadIdx.x;
@@ -215,31 +216,32 @@ __global__ __launch_bounds__(256) void cull_mask_kernel(const CullParams p) {
       }
     }
     const uint64_t word = __ballot(v);
-    if (lane == 0u) ws.mask[(uint64_t)blk * kWordsPerBlock + k * 4u + wv] = word;
-    cnt += (uint32_t)__popcll(word);
+    if (lane == 0u) {
+      ws.mask[(uint64_t)blk * kWordsPerBlock + k * 4u + wv] = word;
+      word_count[k * 4u + wv] = (uint32_t)__popcll(word);
+    }
     if (k == 0u && threadIdx.x == 0u) ws.block_mesh[blk] = in[0] ? min(mesh, p.mesh_count - 1u) : p.mesh_count - 1u;
   }
-  if (lane == 0u) wave_count[wv] = cnt;
   __syncthreads();
-  if (threadIdx.x == 0u) {
-    ws.block_count[blk] = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
-    if (blk == gridDim.x - 1u) ws.block_mesh[gridDim.x] = p.mesh_count - 1u;
+  if (threadIdx.x < kWordsPerBlock) {
+    // exclusive prefix over the 16 word counts (one lane each, 16 LDS reads at most)
+    uint32_t before = 0;
+    for (uint32_t k = 0; k < threadIdx.x; ++k) before += word_count[k];
+    ws.word_prefix[(uint64_t)blk * kWordsPerBlock + threadIdx.x] = (uint16_t)before;
+    if (threadIdx.x == kWordsPerBlock - 1u) ws.block_count[blk] = before + word_count[kWordsPerBlock - 1u];
   }
+  if (threadIdx.x == 0u && blk == gridDim.x - 1u) ws.block_mesh[gridDim.x] = p.mesh_count - 1u;
   if (bad && p.error_flag) *p.error_flag = 1u;
 }
 
-// Global rank (number of visible instances with index < i).
+// Global rank (number of visible instances with index < i): three independent loads.
 __device__ __forceinline__ uint32_t rank_before(const DetWorkspace& ws, uint32_t i) {
   const uint32_t blk = i / kBlockInstances;
-  const uint32_t r = i % kBlockInstances;
-  // instance order inside a block is row-major over (k, wave, lane): word index = r / 64
-  uint32_t g = ws.block_prefix[blk];
-  const uint64_t* words = ws.mask + (uint64_t)blk * kWordsPerBlock;
-  const uint32_t w = r >> 6;
-  for (uint32_t k = 0; k < w; ++k) g += (uint32_t)__popcll(words[k]);
-  const uint32_t bit = r & 63u;
-  if (bit) g += (uint32_t)__popcll(words[w] & ((1ull << bit) - 1ull));
-  return g;
+  const uint32_t w = (i % kBlockInstances) >> 6;  // instance order inside a block is row-major over (k, wave, lane)
+  const uint32_t bit = i & 63u;
+  const uint64_t word = ws.mask[(uint64_t)blk * kWordsPerBlock + w];
+  const uint32_t below = bit ? (uint32_t)__popcll(word & ((1ull << bit) - 1ull)) : 0u;
+  return ws.block_prefix[blk] + ws.word_prefix[(uint64_t)blk * kWordsPerBlock + w] + below;
 }
 
 // Pass C (same launch as B): rank of every mesh boundary, then the commands.
@@ -256,7 +258,8 @@ __device__ __forceinline__ void mesh_rank_and_cmd(const CullParams& p, const Det
   p.cmd_out[m] = c;
 }
 
-// Pass B: exclusive scan of the block counts by one 1024-thread block.
+// Pass B: exclusive scan of the block counts by one 1024-thread block, four counts per thread and pass
+// (a single pass covers 2^22 instances), followed by pass C.
 __global__ __launch_bounds__(1024) void cull_scan_kernel(const CullParams p, uint32_t nblk) {
   __shared__ uint32_t wave_sum[16];
   __shared__ uint32_t carry_s;
@@ -264,11 +267,13 @@ __global__ __launch_bounds__(1024) void cull_scan_kernel(const CullParams p, uin
   const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
   if (threadIdx.x == 0u) carry_s = 0u;
   __syncthreads();
-  for (uint32_t base = 0; base < nblk; base += 1024u) {
-    const uint32_t i = base + threadIdx.x;
-    const uint32_t v = (i < nblk) ? ws.block_count[i] : 0u;
-    // inclusive wave scan
-    uint32_t s = v;
+  for (uint32_t base = 0; base < nblk; base += 4096u) {
+    const uint32_t i = base + threadIdx.x * 4u;
+    uint32_t v[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) v[k] = (i + k < nblk) ? ws.block_count[i + k] : 0u;
+    const uint32_t mine = (v[0] + v[1]) + (v[2] + v[3]);
+    uint32_t s = mine;  // inclusive wave scan
 #pragma unroll
     for (uint32_t d = 1; d < 64u; d <<= 1) {
       const uint32_t o = __shfl_up(s, d);
@@ -279,9 +284,14 @@ __global__ __launch_bounds__(1024) void cull_scan_kernel(const CullParams p, uin
     uint32_t woff = 0;
     for (uint32_t k = 0; k < wv; ++k) woff += wave_sum[k];
     const uint32_t carry = carry_s;
-    if (i < nblk) ws.block_prefix[i] = carry + woff + s - v;
+    uint32_t run = carry + woff + s - mine;
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) {
+      if (i + k < nblk) ws.block_prefix[i + k] = run;
+      run += v[k];
+    }
     __syncthreads();
-    if (threadIdx.x == 1023u) carry_s = carry + woff + s;
+    if (threadIdx.x == 1023u) carry_s = run;
     __syncthreads();
   }
   if (threadIdx.x == 0u) ws.block_prefix[nblk] = carry_s;
@@ -292,32 +302,20 @@ __global__ __launch_bounds__(1024) void cull_scan_kernel(const CullParams p, uin
 
 // Pass D: scatter.  visible[mesh_base[m] + (g - mesh_rank[m])] = i, ascending in i.
 __global__ __launch_bounds__(256) void cull_scatter_kernel(const CullParams p) {
-  __shared__ uint32_t word_prefix[kWordsPerBlock + 1];
-  __shared__ uint64_t word_s[kWordsPerBlock];
   const DetWorkspace ws = carve(p.workspace, p.instance_count, p.mesh_count);
   const uint32_t blk = blockIdx.x;
   const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
-  if (threadIdx.x < kWordsPerBlock) word_s[threadIdx.x] = ws.mask[(uint64_t)blk * kWordsPerBlock + threadIdx.x];
-  __syncthreads();
-  if (threadIdx.x == 0u) {
-    uint32_t acc = ws.block_prefix[blk];
-    for (uint32_t k = 0; k < kWordsPerBlock; ++k) {
-      word_prefix[k] = acc;
-      acc += (uint32_t)__popcll(word_s[k]);
-    }
-    word_prefix[kWordsPerBlock] = acc;
-  }
-  __syncthreads();
-  if (word_prefix[kWordsPerBlock] == word_prefix[0]) return;  // nothing visible in this block
+  if (ws.block_count[blk] == 0u) return;  // nothing visible in this block
+  const uint32_t block_before = ws.block_prefix[blk];
   const uint32_t m_first = ws.block_mesh[blk];
   const uint32_t m_last = ws.block_mesh[blk + 1u];
 #pragma unroll
   for (uint32_t k = 0; k < kPerLane; ++k) {
     const uint32_t w = k * 4u + wv;
-    const uint64_t word = word_s[w];
+    const uint64_t word = ws.mask[(uint64_t)blk * kWordsPerBlock + w];
     if ((word >> lane) & 1ull) {
       const uint32_t i = blk * kBlockInstances + w * 64u + lane;
-      const uint32_t g = word_prefix[w] + rank_in(word);
+      const uint32_t g = block_before + ws.word_prefix[(uint64_t)blk * kWordsPerBlock + w] + rank_in(word);
       // largest m in [m_first, m_last] with mesh_base[m] <= i
       uint32_t lo = m_first, hi = m_last;
       while (lo < hi) {
@@ -335,7 +333,7 @@ __global__ __launch_bounds__(256) void cull_scatter_kernel(const CullParams p) {
 uint64_t vkr_cull_workspace_size(uint64_t n, uint32_t m) {
   const uint64_t nblk = (n + kBlockInstances - 1) / kBlockInstances;
   return align_up(nblk * kWordsPerBlock * 8, 256) + align_up(nblk * 4, 256) + 2 * align_up((nblk + 1) * 4, 256) +
-         align_up(((uint64_t)m + 1) * 4, 256);
+         align_up(((uint64_t)m + 1) * 4, 256) + align_up(nblk * kWordsPerBlock * 2, 256);
 }
 
 hipError_t vkr_launch_cull_atomic(const CullParams& p, hipStream_t stream) {

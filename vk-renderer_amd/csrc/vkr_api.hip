@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -170,7 +171,12 @@ int32_t run_deferred(vkr_context* ctx, const vkr_deferred_args* a) {
   const uint32_t full_h = a->full_height ? a->full_height : h;
   if ((uint64_t)a->row_offset + h > full_h)
     return fail(VKR_ERR_INVALID_ARGUMENT, "row_offset %u + height %u exceeds full_height %u", a->row_offset, h, full_h);
-  if (a->flags & ~VKR_DEFERRED_RADIUS_CUTOFF) return fail(VKR_ERR_INVALID_ARGUMENT, "unknown flags 0x%x", a->flags);
+  if (a->flags & ~(VKR_DEFERRED_RADIUS_CUTOFF | VKR_DEFERRED_NO_TILE_LISTS)) return fail(VKR_ERR_INVALID_ARGUMENT, "unknown flags 0x%x", a->flags);
+  if (a->flags & VKR_DEFERRED_RADIUS_CUTOFF) {
+    const float r = a->push[3];
+    // the in-kernel cutoff is the exact step clamp((r^2 - d^2) * 2^80): r^2 must stay within its exact range
+    if (!(r >= 1e-8f && (r <= 1e7f || std::isinf(r)))) return fail(VKR_ERR_INVALID_ARGUMENT, "pointLightRadius %g outside [1e-8, 1e7] (or +inf)", (double)r);
+  }
 
   DeferredParams p{};
   p.albedo = static_cast<const uint8_t*>(a->albedo.device);
