@@ -69,6 +69,9 @@ VKR_API const char* vkr_last_error(void);
 /* Fills a NUL-terminated description "<name> <gcn arch> CUs=<n> clock=<MHz>". */
 VKR_API int32_t vkr_context_device_info(vkr_context* ctx, char* out, size_t out_bytes, int32_t* out_cu_count,
                                          int32_t* out_clock_mhz);
+/* Runs the library's device self-checks (currently: the resolve's correctly-rounded division against
+ * IEEE division on `samples` operand pairs) and returns the number of failures in *out_failures. */
+VKR_API int32_t vkr_context_self_test(vkr_context* ctx, uint32_t samples, uint32_t* out_failures);
 /* The HIP stream (hipStream_t) all work of this context is ordered on. */
 VKR_API int32_t vkr_context_stream(vkr_context* ctx, void** out_hip_stream);
 

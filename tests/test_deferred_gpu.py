@@ -71,6 +71,12 @@ def test_rgba16f_output(vkr, synth, oracle, ctx):
     assert np.all(got[..., 3] == np.float16(1.0))
 
 
+def test_device_self_test(ctx):
+    """The resolve's shared-reciprocal division must equal IEEE division bit for bit (positions are
+    reproduced exactly; a single ulp there is visible at 1e-4 for lights close to far surfaces)."""
+    assert ctx.self_test(1 << 24) == 0
+
+
 def test_zero_lights_is_ambient(vkr, synth, ctx):
     case = synth.deferred_case(40, 10, 0)
     got, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT)

@@ -42,19 +42,23 @@ for name, b in variants:
 }}''')
 src.append('''typedef void (*kern_t)(unsigned long long*, int, float);
 void run(const char* name, kern_t k, int w, unsigned long long* d) {
-  const int iters = 400, blocks = 256 * w, nwaves = blocks * 4;
+  const int iters = 2000, blocks = 256 * w, nwaves = blocks * 4;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, d, iters, 1.5f);
+  hipEventRecord(e0);
   hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, d, iters, 1.5f);
+  hipEventRecord(e1);
   hipDeviceSynchronize();
+  float ms; hipEventElapsedTime(&ms, e0, e1);
   std::vector<unsigned long long> h(nwaves);
   hipMemcpy(h.data(), d, nwaves * 8, hipMemcpyDeviceToHost);
   std::sort(h.begin(), h.end());
   const double med = (double)h[nwaves / 2] / iters / w;  // SIMD cycles per body
-  printf("%-12s w=%d  SIMD cycles per 256-instr body: %.1f   (extra over plain per transcendental: %.1f)\\n", name, w, med, (med - 256 * 1.95) / 16.0 + 1.95);
+  printf("%-12s w=%d  ticks per body: %.1f   wall ns per body per SIMD: %.1f\\n", name, w, med, ms * 1e6 / (iters * (double)w));
 }
 int main() {
   unsigned long long* d; hipMalloc(&d, 8 * 256 * 8 * 4 * 2);
-  for (int w : {3, 4}) {''')
+  for (int w : {2, 4, 6, 8}) {''')
 for name, _ in variants:
     src.append(f'    run("{name}", k_{name}, w, d);')
 src.append('    printf("\\n");\n  }\n  return 0;\n}')

@@ -72,6 +72,7 @@ EXPORTS = {
     "vkr_context_destroy": (C.c_int32, [_P]),
     "vkr_last_error": (C.c_char_p, []),
     "vkr_context_device_info": (C.c_int32, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "vkr_context_self_test": (C.c_int32, [_P, C.c_uint32, C.POINTER(C.c_uint32)]),
     "vkr_context_stream": (C.c_int32, [_P, _PP]),
     "vkr_buffer_create": (C.c_int32, [_P, C.c_uint64, C.c_uint32, _PP]),
     "vkr_buffer_wrap": (C.c_int32, [_P, _P, C.c_uint64, _PP]),
@@ -319,6 +320,12 @@ class Context:
         cu, mhz = C.c_int32(), C.c_int32()
         _check(lib().vkr_context_device_info(self.handle, buf, 256, C.byref(cu), C.byref(mhz)))
         return {"name": buf.value.decode(), "cu_count": cu.value, "clock_mhz": mhz.value}
+
+    def self_test(self, samples: int = 1 << 22) -> int:
+        """Number of failed device self-checks (0 = all good)."""
+        n = C.c_uint32()
+        _check(lib().vkr_context_self_test(self.handle, samples, C.byref(n)))
+        return int(n.value)
 
     def stream(self) -> int:
         p = C.c_void_p()

@@ -32,7 +32,9 @@
 // pairs advance in lockstep.  A transcendental costs as much as ~8 plain instructions in this mix
 // (measured by ablation on this kernel: 2.07 ms with the 16 per iteration replaced by moves, 2.87 ms
 // with them); a degree-5 polynomial for sqrt(1 + a2 c^2) measured the same as the instruction, so
-// the instruction (1 ulp) stays.
+// the instruction (1 ulp) stays.  Where the four sit in the stream (grouped as here, left to the
+// compiler, or spread one per ~14 plain instructions with sched_group_barrier) moved the kernel by
+// less than +-4 %.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -77,6 +79,25 @@ VKR_TRANS4(rsq4, "v_rsq_f32")
 VKR_TRANS4(sqrt4, "v_sqrt_f32")
 VKR_TRANS4(rcp4, "v_rcp_f32")
 #undef VKR_TRANS4
+
+// Correctly rounded a/b for operands whose quotient and reciprocal stay in the normal range (the
+// compiler's own division is this same arithmetic wrapped in v_div_scale / v_div_fmas / v_div_fixup,
+// which only matter for denormal, huge or special operands and issue at half rate or worse).
+// The refined reciprocal is shared by every division by the same b.
+struct ExactRcp {
+  float b, r;
+};
+__device__ __forceinline__ ExactRcp exact_rcp(float b) {
+  float r = rcp_(b);
+  r = fma_(fma_(-b, r, 1.0f), r, r);
+  return {b, r};
+}
+__device__ __forceinline__ float exact_div(float a, const ExactRcp& d) {
+  float q = a * d.r;
+  q = fma_(fma_(-d.b, q, a), d.r, q);
+  q = fma_(fma_(-d.b, q, a), d.r, q);
+  return q;
+}
 
 struct Pixel {
   // geometry
@@ -179,12 +200,15 @@ struct Material {
 };
 
 // deferred.comp:99-118: everything that does not depend on the light.
-__device__ __forceinline__ void setup_pixel(Pixel& s, Material& m, const DeferredParams& p, uint32_t x, uint32_t y_full,
-                                            float depth, uint32_t albedo, uint32_t material, uint32_t nrm_lo,
+__device__ __forceinline__ void setup_pixel(Pixel& s, Material& m, const DeferredParams& p, const ExactRcp& by_width,
+                                            const ExactRcp& by_height, uint32_t x, uint32_t y_full, float depth, uint32_t albedo, uint32_t material, uint32_t nrm_lo,
                                             uint32_t nrm_hi) {
-  // :99-103 in the reference's binary32 order (no contraction in this file)
-  const float u = ((float)x + 0.5f) / (float)p.width;
-  const float v = ((float)y_full + 0.5f) / (float)p.full_height;
+  // :99-103 in the reference's binary32 order, true divisions included (no contraction in this file).
+  // Position reconstruction is ill-conditioned twice over: the w row cancels as depth -> 1, and a light
+  // 0.4 units from a surface 400 units out turns one ulp of position into 1.5e-4 of 1/d^2.  So the
+  // position is reproduced bit for bit rather than to within rounding.
+  const float u = exact_div((float)x + 0.5f, by_width);
+  const float v = exact_div((float)y_full + 0.5f, by_height);
   const float cx = u * 2.0f - 1.0f;
   const float cy = v * 2.0f - 1.0f;
   const float* M = p.inv_vp;
@@ -192,9 +216,10 @@ __device__ __forceinline__ void setup_pixel(Pixel& s, Material& m, const Deferre
   const float wy = ((M[1] * cx + M[5] * cy) + M[9] * depth) + M[13];
   const float wz = ((M[2] * cx + M[6] * cy) + M[10] * depth) + M[14];
   const float ww = ((M[3] * cx + M[7] * cy) + M[11] * depth) + M[15];
-  s.px = wx / ww;
-  s.py = wy / ww;
-  s.pz = wz / ww;
+  const ExactRcp by_w = exact_rcp(ww);
+  s.px = exact_div(wx, by_w);
+  s.py = exact_div(wy, by_w);
+  s.pz = exact_div(wz, by_w);
 
   const float k255 = 1.0f / 255.0f;
   m.alb[0] = (float)(albedo & 0xFFu) * k255;
@@ -275,7 +300,7 @@ __device__ __forceinline__ uint32_t quantize_unorm8(float c) {
 // settles on unprompted.
 template <int kOutMode, bool kRadius, bool kTile>
 __global__ __launch_bounds__(256, 4) void deferred_kernel(const DeferredParams p) {
-  __shared__ float4 s_light[2 * kChunk];
+  __shared__ float4 s_light[2 * kChunk + 4];  // +1 pair: the prefetch of the last iteration reads past the list
   __shared__ float s_red[8];
   __shared__ uint32_t s_cnt[4];
   const uint32_t t = threadIdx.x;
@@ -392,6 +417,7 @@ __global__ __launch_bounds__(256, 4) void deferred_kernel(const DeferredParams p
     reach = sqrt_(p.radius2) + pad;
   }
 
+  const ExactRcp by_width = exact_rcp((float)p.width), by_height = exact_rcp((float)p.full_height);
   uint32_t packed[4];
   float rgb[4][3];
   bool list_complete = false;  // kTile: the list built for the first pixel pair holds every reaching light
@@ -402,19 +428,20 @@ __global__ __launch_bounds__(256, 4) void deferred_kernel(const DeferredParams p
     Pixel s[2];
     Material m[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) setup_pixel(s[i], m[i], p, lx + g + i, y_full, dep[g + i], alb[g + i], mat[g + i], nlo[g + i], nhi[g + i]);
+    for (int i = 0; i < 2; ++i) setup_pixel(s[i], m[i], p, by_width, by_height, lx + g + i, y_full, dep[g + i], alb[g + i], mat[g + i], nlo[g + i], nhi[g + i]);
 
     // shades the first `count` records of s_light (count even, > 0)
     auto shade_list = [&](uint32_t count) {
-      float4 pa = s_light[0], ca = s_light[1], pb = s_light[2], cb = s_light[3];
+      const float4* rec = s_light;
+      float4 pa = rec[0], ca = rec[1], pb = rec[2], cb = rec[3];
       for (uint32_t j = 0; j < count; j += 2u) {
         const Light A{pa.x, pa.y, pa.z, ca.x, ca.y, ca.z};
         const Light B{pb.x, pb.y, pb.z, cb.x, cb.y, cb.z};
-        const uint32_t jn = min(j + 2u, count - 2u);  // last iteration re-reads its own pair
-        pa = s_light[2u * jn];
-        ca = s_light[2u * jn + 1u];
-        pb = s_light[2u * jn + 2u];
-        cb = s_light[2u * jn + 3u];
+        rec += 4;  // next pair (one pair beyond the list on the last trip: read, never used)
+        pa = rec[0];
+        ca = rec[1];
+        pb = rec[2];
+        cb = rec[3];
         shade4<kRadius>(s[0], s[1], A, B, kc);
       }
     };
@@ -532,6 +559,29 @@ __global__ __launch_bounds__(256, 4) void deferred_kernel(const DeferredParams p
   }
 }
 
+// Device self-check of exact_div against the compiler's IEEE division over the operand ranges the
+// resolve uses: counts mismatching bit patterns.
+__global__ void exact_div_check_kernel(uint32_t n, uint32_t seed, uint32_t* mismatches) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t h = (i + 1u) * 2654435761u ^ seed;
+  auto next = [&]() {
+    h ^= h << 13; h ^= h >> 17; h ^= h << 5;
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+  };
+  const float u0 = next(), u1 = next(), u2 = next();
+  // divisor: w of the unprojection (~1e-4 .. 16), an image extent (1 .. 65536), or any value in [2^-20, 2^20]
+  float b, a;
+  switch (i % 3u) {
+    case 0: b = 1e-4f + 16.0f * u0 * u0; a = (u1 - 0.5f) * 4000.0f; break;
+    case 1: b = floorf(1.0f + 65535.0f * u0); a = floorf(65536.0f * u1) + 0.5f; break;
+    default: b = exp2f(40.0f * u0 - 20.0f) * (1.0f + u2); a = exp2f(40.0f * u1 - 20.0f) * (u2 < 0.5f ? -1.0f : 1.0f); break;
+  }
+  const float want = a / b;
+  const float got = exact_div(a, exact_rcp(b));
+  if (__float_as_uint(want) != __float_as_uint(got)) atomicAdd(mismatches, 1u);
+}
+
 template <int kOutMode>
 hipError_t launch_mode(const DeferredParams& p, hipStream_t stream) {
   const dim3 grid((p.width + 31u) / 32u, (p.height + 31u) / 32u, 1u);
@@ -546,6 +596,11 @@ hipError_t launch_mode(const DeferredParams& p, hipStream_t stream) {
 }
 
 }  // namespace
+
+hipError_t vkr_launch_exact_div_check(uint32_t n, uint32_t seed, uint32_t* mismatches, hipStream_t stream) {
+  hipLaunchKernelGGL(exact_div_check_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, n, seed, mismatches);
+  return hipGetLastError();
+}
 
 hipError_t vkr_launch_deferred(const DeferredParams& p, hipStream_t stream) {
   switch (p.out_mode) {

@@ -384,6 +384,20 @@ int32_t vkr_context_device_info(vkr_context* ctx, char* out, size_t out_bytes, i
   return VKR_OK;
 }
 
+int32_t vkr_context_self_test(vkr_context* ctx, uint32_t samples, uint32_t* out_failures) {
+  if (!ctx || !out_failures) return fail(VKR_ERR_INVALID_ARGUMENT, "null argument");
+  VKR_HIP(hipSetDevice(ctx->device));
+  uint32_t* d = nullptr;
+  VKR_HIP(hipMalloc(reinterpret_cast<void**>(&d), sizeof(uint32_t)));
+  hipError_t e = hipMemsetAsync(d, 0, sizeof(uint32_t), ctx->stream);
+  if (e == hipSuccess && samples) e = vkr_launch_exact_div_check(samples, 0x9E3779B9u, d, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(out_failures, d, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(VKR_ERR_DEVICE, "self test: %s", hipGetErrorString(e));
+  return VKR_OK;
+}
+
 int32_t vkr_context_stream(vkr_context* ctx, void** out_hip_stream) {
   if (!ctx || !out_hip_stream) return fail(VKR_ERR_INVALID_ARGUMENT, "null argument");
   *out_hip_stream = ctx->stream;

@@ -28,6 +28,7 @@ struct DeferredParams {
 };
 
 hipError_t vkr_launch_deferred(const DeferredParams& p, hipStream_t stream);
+hipError_t vkr_launch_exact_div_check(uint32_t n, uint32_t seed, uint32_t* mismatches, hipStream_t stream);
 
 struct DrawCmd {
   uint32_t indexCount, instanceCount, firstIndex;
