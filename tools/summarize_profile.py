@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/prof_<tag>/ (written by tools/profile_round.sh) into profiles/<tag>_*.
+
+  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of `python bench.py`
+  profiles/<tag>_pmc.json           per-kernel counter averages + HBM traffic per launch
+HBM traffic follows the gfx950 rules: FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE counts a wide
+coalesced read stream at half its bytes (128-byte requests tallied as 64), so it is doubled; WRITE_SIZE
+is exact for 16-byte-per-lane stores.  The two were collected in separate passes.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0]
+shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+bench_line = [l for l in open(os.path.join(src, "bench_under_trace.log")) if l.startswith("{")]
+if bench_line:
+    open(os.path.join(dst, f"{tag}_bench_under_trace.json"), "w").write(bench_line[-1])
+
+out = collections.defaultdict(dict)
+for f in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    dur = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if k.startswith("__amd"):
+            continue
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    for k, cs in agg.items():
+        short = k.split("(")[0].split("::")[-1].strip() + ("<" + k.split("<")[1].split(">")[0] + ">" if "<" in k else "")
+        for c, v in cs.items():
+            # skip the first dispatches (clock ramp / cold caches)
+            vv = v[len(v) // 3:]
+            out[short][c] = sum(vv) / len(vv)
+        d = dur[k][len(dur[k]) // 3:]
+        out[short].setdefault("duration_us_under_pmc", {})[os.path.basename(os.path.dirname(os.path.dirname(f)))] = sum(d) / len(d) / 1e3
+
+for k, c in out.items():
+    if "FETCH_SIZE" in c:
+        c["hbm_read_bytes_per_launch"] = c["FETCH_SIZE"] * 1024 * 2
+    if "WRITE_SIZE" in c:
+        c["hbm_write_bytes_per_launch"] = c["WRITE_SIZE"] * 1024
+    if "hbm_read_bytes_per_launch" in c and "hbm_write_bytes_per_launch" in c:
+        c["hbm_traffic_bytes_per_launch"] = c["hbm_read_bytes_per_launch"] + c["hbm_write_bytes_per_launch"]
+    if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+        c["l2_hit_rate"] = c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1)
+    if "GRBM_GUI_ACTIVE" in c and "pmc_SQ_WAVES" in c.get("duration_us_under_pmc", {}):
+        c["clock_GHz_under_pmc"] = c["GRBM_GUI_ACTIVE"] / 8 / (c["duration_us_under_pmc"]["pmc_SQ_WAVES"] * 1e3)
+json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
+print(json.dumps(out, indent=1, sort_keys=True))

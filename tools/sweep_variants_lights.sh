@@ -1,0 +1,7 @@
+#!/bin/bash
+# Times each tuning variant of the library on the deferred workload at several light counts.
+for L in 0 1 13 64 256; do
+for f in vk-renderer_amd/lib/variants/libvkr_*.so; do
+  VKR_LIB_PATH=$PWD/$f timeout -k 10 120 python -u bench.py --steps 30 --warmup 10 --lights $L --no-cull --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('L=$L $f', round(d['value'],3), 'Gpix/s', round(d['roofline']['kernel_ms'],4), 'ms')" || exit 1
+done
+done

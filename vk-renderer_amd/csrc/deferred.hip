@@ -301,6 +301,7 @@ __device__ __forceinline__ uint32_t quantize_unorm8(float c) {
 template <int kOutMode, bool kRadius, bool kTile>
 __global__ __launch_bounds__(256, 4) void deferred_kernel(const DeferredParams p) {
   __shared__ float4 s_light[2 * kChunk + 4];  // +1 pair: the prefetch of the last iteration reads past the list
+  __shared__ uint32_t s_stash[10][256];
   __shared__ float s_red[8];
   __shared__ uint32_t s_cnt[4];
   const uint32_t t = threadIdx.x;
@@ -318,11 +319,26 @@ __global__ __launch_bounds__(256, 4) void deferred_kernel(const DeferredParams p
   const uint4 nrmA = *reinterpret_cast<const uint4*>(p.normal + (size_t)ly * p.pitch_normal + (size_t)lx * 8u);
   const uint4 nrmB = *reinterpret_cast<const uint4*>(p.normal + (size_t)ly * p.pitch_normal + (size_t)lx * 8u + 16u);
 
-  const uint32_t alb[4] = {alb4.x, alb4.y, alb4.z, alb4.w};
-  const uint32_t mat[4] = {mat4.x, mat4.y, mat4.z, mat4.w};
-  const float dep[4] = {dep4.x, dep4.y, dep4.z, dep4.w};
-  const uint32_t nlo[4] = {nrmA.x, nrmA.z, nrmB.x, nrmB.z};
-  const uint32_t nhi[4] = {nrmA.y, nrmA.w, nrmB.y, nrmB.w};
+  // The first pixel pair is set up from registers; the raw words of the second pair wait in LDS (one
+  // dword column per lane: conflict-free) instead of occupying ten VGPRs across the first light loop,
+  // where the register allocator would otherwise spill them to scratch memory (HBM traffic).
+  uint32_t alb[2] = {alb4.x, alb4.y};
+  uint32_t mat[2] = {mat4.x, mat4.y};
+  float dep[2] = {dep4.x, dep4.y};
+  uint32_t nlo[2] = {nrmA.x, nrmA.z};
+  uint32_t nhi[2] = {nrmA.y, nrmA.w};
+  s_stash[0][t] = alb4.z;
+  s_stash[1][t] = alb4.w;
+  s_stash[2][t] = mat4.z;
+  s_stash[3][t] = mat4.w;
+  s_stash[4][t] = __float_as_uint(dep4.z);
+  s_stash[5][t] = __float_as_uint(dep4.w);
+  s_stash[6][t] = nrmB.x;
+  s_stash[7][t] = nrmB.y;
+  s_stash[8][t] = nrmB.z;
+  s_stash[9][t] = nrmB.w;
+  float dmin_lane = fminf(fminf(dep4.x, dep4.y), fminf(dep4.z, dep4.w));
+  float dmax_lane = fmaxf(fmaxf(dep4.x, dep4.y), fmaxf(dep4.z, dep4.w));
 
   const float4* __restrict__ lights = reinterpret_cast<const float4*>(p.lights);
   const uint32_t L = p.light_count;
@@ -340,8 +356,7 @@ __global__ __launch_bounds__(256, 4) void deferred_kernel(const DeferredParams p
   float face[4][4] = {};  // outward unit normals and offsets of the pyramid's side faces
   float reach = 0.0f;     // radius + reconstruction pad
   if (kTile) {
-    float dmin = fminf(fminf(dep[0], dep[1]), fminf(dep[2], dep[3]));
-    float dmax = fmaxf(fmaxf(dep[0], dep[1]), fmaxf(dep[2], dep[3]));
+    float dmin = dmin_lane, dmax = dmax_lane;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
       dmin = fminf(dmin, __shfl_xor(dmin, off));
@@ -427,8 +442,20 @@ __global__ __launch_bounds__(256, 4) void deferred_kernel(const DeferredParams p
   for (int g = 0; g < 4; g += 2) {
     Pixel s[2];
     Material m[2];
+    if (g != 0) {
+      alb[0] = s_stash[0][t];
+      alb[1] = s_stash[1][t];
+      mat[0] = s_stash[2][t];
+      mat[1] = s_stash[3][t];
+      dep[0] = __uint_as_float(s_stash[4][t]);
+      dep[1] = __uint_as_float(s_stash[5][t]);
+      nlo[0] = s_stash[6][t];
+      nhi[0] = s_stash[7][t];
+      nlo[1] = s_stash[8][t];
+      nhi[1] = s_stash[9][t];
+    }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) setup_pixel(s[i], m[i], p, by_width, by_height, lx + g + i, y_full, dep[g + i], alb[g + i], mat[g + i], nlo[g + i], nhi[g + i]);
+    for (int i = 0; i < 2; ++i) setup_pixel(s[i], m[i], p, by_width, by_height, lx + g + i, y_full, dep[i], alb[i], mat[i], nlo[i], nhi[i]);
 
     // shades the first `count` records of s_light (count even, > 0)
     auto shade_list = [&](uint32_t count) {
