@@ -12,6 +12,7 @@ import csv
 import glob
 import json
 import os
+import re
 import shutil
 import sys
 
@@ -38,7 +39,8 @@ for f in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     for k, cs in agg.items():
-        short = k.split("(")[0].split("::")[-1].strip() + ("<" + k.split("<")[1].split(">")[0] + ">" if "<" in k else "")
+        m = re.search(r"(\w+)(<[^>]*>)?\([^()]*\)$", k)  # function name (+ template arguments) before the parameter list
+        short = (m.group(1) + (m.group(2) or "")) if m else k
         for c, v in cs.items():
             # skip the first dispatches (clock ramp / cold caches)
             vv = v[len(v) // 3:]

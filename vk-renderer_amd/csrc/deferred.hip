@@ -194,23 +194,20 @@ __device__ __forceinline__ void shade4(Pixel& a, Pixel& b, const Light& A, const
   }
 }
 
-struct Material {
-  float alb[3];
-  float rough, metal;
-};
+// deferred.comp:99-100: clip-space coordinate of a pixel centre, true division included.
+__device__ __forceinline__ float clip_coord(uint32_t i, const ExactRcp& by_extent) {
+  return exact_div((float)i + 0.5f, by_extent) * 2.0f - 1.0f;
+}
+
+__device__ __forceinline__ float unorm8(uint32_t word, int byte) { return (float)((word >> (8 * byte)) & 0xFFu) * (1.0f / 255.0f); }
 
 // deferred.comp:99-118: everything that does not depend on the light.
-__device__ __forceinline__ void setup_pixel(Pixel& s, Material& m, const DeferredParams& p, const ExactRcp& by_width,
-                                            const ExactRcp& by_height, uint32_t x, uint32_t y_full, float depth, uint32_t albedo, uint32_t material, uint32_t nrm_lo,
-                                            uint32_t nrm_hi) {
+__device__ __forceinline__ void setup_pixel(Pixel& s, const DeferredParams& p, float cx, float cy, float depth, uint32_t material,
+                                            uint32_t nrm_lo, uint32_t nrm_hi) {
   // :99-103 in the reference's binary32 order, true divisions included (no contraction in this file).
   // Position reconstruction is ill-conditioned twice over: the w row cancels as depth -> 1, and a light
   // 0.4 units from a surface 400 units out turns one ulp of position into 1.5e-4 of 1/d^2.  So the
   // position is reproduced bit for bit rather than to within rounding.
-  const float u = exact_div((float)x + 0.5f, by_width);
-  const float v = exact_div((float)y_full + 0.5f, by_height);
-  const float cx = u * 2.0f - 1.0f;
-  const float cy = v * 2.0f - 1.0f;
   const float* M = p.inv_vp;
   const float wx = ((M[0] * cx + M[4] * cy) + M[8] * depth) + M[12];
   const float wy = ((M[1] * cx + M[5] * cy) + M[9] * depth) + M[13];
@@ -221,12 +218,7 @@ __device__ __forceinline__ void setup_pixel(Pixel& s, Material& m, const Deferre
   s.py = exact_div(wy, by_w);
   s.pz = exact_div(wz, by_w);
 
-  const float k255 = 1.0f / 255.0f;
-  m.alb[0] = (float)(albedo & 0xFFu) * k255;
-  m.alb[1] = (float)((albedo >> 8) & 0xFFu) * k255;
-  m.alb[2] = (float)((albedo >> 16) & 0xFFu) * k255;
-  m.rough = (float)((material >> 8) & 0xFFu) * k255;
-  m.metal = (float)((material >> 16) & 0xFFu) * k255;
+  const float rough = unorm8(material, 1);
 
   // :108 normal = -normalize(n)
   const __half2 h01 = __builtin_bit_cast(__half2, nrm_lo);
@@ -257,27 +249,31 @@ __device__ __forceinline__ void setup_pixel(Pixel& s, Material& m, const Deferre
   s.vn = fma_(vz, s.nz, fma_(vy, s.ny, vx * s.nx));
 
   // :116 alpha = max(r*r, 0.0064)
-  const float alpha = fmaxf(m.rough * m.rough, kAlphaFloor);
+  const float alpha = fmaxf(rough * rough, kAlphaFloor);
   s.a2 = alpha * alpha;
-  s.rh = 0.5f * m.rough;
-  s.ebm1 = fma_(0.5f, m.rough, -1.0f);
+  s.rh = 0.5f * rough;
+  s.ebm1 = fma_(0.5f, rough, -1.0f);
   s.pv = pow5_(clamp01_(1.0f - s.vn));
 #pragma unroll
   for (int k = 0; k < 3; ++k) s.ad[k] = s.as0[k] = s.as1[k] = 0.0f;
 }
 
-// Combines the three light sums into the pixel colour (deferred.comp:107,114-115,127-128).
-__device__ __forceinline__ void finish_pixel(const Pixel& s, const Material& m, float out[3]) {
+// Combines the three light sums into the pixel colour (deferred.comp:107,114-115,127-128).  The
+// albedo and material words are decoded here, after the light loop, so that nothing of them occupies
+// registers during it.
+__device__ __forceinline__ void finish_pixel(const Pixel& s, uint32_t albedo, uint32_t material, float out[3]) {
+  const float rough = unorm8(material, 1), metal = unorm8(material, 2);
   const bool front = s.vn > kEarlyOut;  // deferred.comp:43,84 (vDotN half of the early-out)
-  const float ef = fma_(const_inv151(), m.rough, 1.0f - m.rough);  // mix(1, 1/1.51, r)
+  const float ef = fma_(const_inv151(), rough, 1.0f - rough);  // mix(1, 1/1.51, r)
   const float kdiff = (kPi * kInvDistFloor) * ef;  // the light sums carry a factor 1e-7
   const float kspec = (s.a2 * kInvDistFloor) * rcp_(kPi * (s.vn + sqrt_(fma_(s.a2, s.vn * s.vn, 1.0f))));
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const float cd = m.alb[k] * (1.0f - m.metal);  // mix(albedo, 0, metal)
-    const float cs = m.alb[k] * m.metal;           // mix(0, albedo, metal)
+    const float alb = unorm8(albedo, k);
+    const float cd = alb * (1.0f - metal);  // mix(albedo, 0, metal)
+    const float cs = alb * metal;           // mix(0, albedo, metal)
     const float lit = fma_(cd * kdiff, s.ad[k], kspec * fma_(cs, s.as0[k], (1.0f - cs) * s.as1[k]));
-    out[k] = fma_(kAmbient, m.alb[k], front ? lit : 0.0f);
+    out[k] = fma_(kAmbient, alb, front ? lit : 0.0f);
   }
 }
 
@@ -301,7 +297,7 @@ __device__ __forceinline__ uint32_t quantize_unorm8(float c) {
 template <int kOutMode, bool kRadius, bool kTile>
 __global__ __launch_bounds__(256, 4) void deferred_kernel(const DeferredParams p) {
   __shared__ float4 s_light[2 * kChunk + 4];  // +1 pair: the prefetch of the last iteration reads past the list
-  __shared__ uint32_t s_stash[10][256];
+  __shared__ uint32_t s_stash[14][256];  // rows: see kRow* below
   __shared__ float s_red[8];
   __shared__ uint32_t s_cnt[4];
   const uint32_t t = threadIdx.x;
@@ -319,24 +315,33 @@ __global__ __launch_bounds__(256, 4) void deferred_kernel(const DeferredParams p
   const uint4 nrmA = *reinterpret_cast<const uint4*>(p.normal + (size_t)ly * p.pitch_normal + (size_t)lx * 8u);
   const uint4 nrmB = *reinterpret_cast<const uint4*>(p.normal + (size_t)ly * p.pitch_normal + (size_t)lx * 8u + 16u);
 
-  // The first pixel pair is set up from registers; the raw words of the second pair wait in LDS (one
-  // dword column per lane: conflict-free) instead of occupying ten VGPRs across the first light loop,
-  // where the register allocator would otherwise spill them to scratch memory (HBM traffic).
-  uint32_t alb[2] = {alb4.x, alb4.y};
-  uint32_t mat[2] = {mat4.x, mat4.y};
+  // Little more than what the light loop itself reads stays in registers across it.  The albedo and
+  // material words of all four pixels (decoded after the loop), the normal words of the second pixel
+  // pair and the first pair's results wait in LDS, one dword column per lane (conflict-free, private to
+  // the lane: no barrier needed).  Left in VGPRs, the register allocator spills part of them to scratch
+  // memory, which is HBM traffic of the order of the output itself.  The rows are kept few: past
+  // 32 KiB of LDS per workgroup the kernel measurably slows down.
+  enum { kRowAlbedo = 0, kRowMaterial = 4, kRowNormal = 8, kRowExtra = 12, kStashRows = 14 };
+  const ExactRcp by_width = exact_rcp((float)p.width), by_height = exact_rcp((float)p.full_height);
+  const float cy = clip_coord(y_full, by_height);
+  float cx[2] = {clip_coord(lx, by_width), clip_coord(lx + 1u, by_width)};
+  const float cx_next[2] = {clip_coord(lx + 2u, by_width), clip_coord(lx + 3u, by_width)};
   float dep[2] = {dep4.x, dep4.y};
+  uint32_t mat[2] = {mat4.x, mat4.y};
   uint32_t nlo[2] = {nrmA.x, nrmA.z};
   uint32_t nhi[2] = {nrmA.y, nrmA.w};
-  s_stash[0][t] = alb4.z;
-  s_stash[1][t] = alb4.w;
-  s_stash[2][t] = mat4.z;
-  s_stash[3][t] = mat4.w;
-  s_stash[4][t] = __float_as_uint(dep4.z);
-  s_stash[5][t] = __float_as_uint(dep4.w);
-  s_stash[6][t] = nrmB.x;
-  s_stash[7][t] = nrmB.y;
-  s_stash[8][t] = nrmB.z;
-  s_stash[9][t] = nrmB.w;
+  s_stash[kRowAlbedo + 0][t] = alb4.x;
+  s_stash[kRowAlbedo + 1][t] = alb4.y;
+  s_stash[kRowAlbedo + 2][t] = alb4.z;
+  s_stash[kRowAlbedo + 3][t] = alb4.w;
+  s_stash[kRowMaterial + 0][t] = mat4.x;
+  s_stash[kRowMaterial + 1][t] = mat4.y;
+  s_stash[kRowMaterial + 2][t] = mat4.z;
+  s_stash[kRowMaterial + 3][t] = mat4.w;
+  s_stash[kRowNormal + 0][t] = nrmB.x;
+  s_stash[kRowNormal + 1][t] = nrmB.y;
+  s_stash[kRowNormal + 2][t] = nrmB.z;
+  s_stash[kRowNormal + 3][t] = nrmB.w;
   float dmin_lane = fminf(fminf(dep4.x, dep4.y), fminf(dep4.z, dep4.w));
   float dmax_lane = fmaxf(fmaxf(dep4.x, dep4.y), fmaxf(dep4.z, dep4.w));
 
@@ -352,10 +357,14 @@ __global__ __launch_bounds__(256, 4) void deferred_kernel(const DeferredParams p
   const uint32_t lane = t & 63u, wv = t >> 6;
 
   // ---- tile bounds (kTile): world-space box around every pixel position of the tile ----------------
-  float box_lo[3] = {0.0f, 0.0f, 0.0f}, box_hi[3] = {0.0f, 0.0f, 0.0f};
-  float face[4][4] = {};  // outward unit normals and offsets of the pyramid's side faces
-  float reach = 0.0f;     // radius + reconstruction pad
+  // s_tile: box_lo[3], box_hi[3], four side faces of the tile's pyramid (outward unit normal + offset),
+  // reach = radius + reconstruction pad.  Block-uniform, so it lives in LDS (broadcast reads) rather
+  // than in 23 VGPRs of every lane.
+  __shared__ float s_tile[23];
   if (kTile) {
+    float box_lo[3] = {0.0f, 0.0f, 0.0f}, box_hi[3] = {0.0f, 0.0f, 0.0f};
+    float face[4][4] = {};
+    float reach = 0.0f;
     float dmin = dmin_lane, dmax = dmax_lane;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -430,32 +439,45 @@ __global__ __launch_bounds__(256, 4) void deferred_kernel(const DeferredParams p
       face[c][3] = -(face[c][0] * near_pt[c][0] + face[c][1] * near_pt[c][1] + face[c][2] * near_pt[c][2]);
     }
     reach = sqrt_(p.radius2) + pad;
+    if (t == 0u) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        s_tile[a] = box_lo[a];
+        s_tile[3 + a] = box_hi[a];
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) s_tile[6 + 4 * c + a] = face[c][a];
+      s_tile[22] = reach;
+    }
+    __syncthreads();
   }
 
-  const ExactRcp by_width = exact_rcp((float)p.width), by_height = exact_rcp((float)p.full_height);
-  uint32_t packed[4];
-  float rgb[4][3];
   bool list_complete = false;  // kTile: the list built for the first pixel pair holds every reaching light
   uint32_t list_count = 0;
+  float last[2][3] = {};  // float outputs: the second pair's colours
 
-#pragma unroll
+  // One copy of the light loop serves both pixel pairs (no unrolling): the loop's issue time moves by
+  // 10 % with the placement of its instructions relative to 32-byte fetch windows, and one copy whose
+  // header is put on a 32-byte boundary (-falign-loops=32 in the build) is the placement that measured best.
+#pragma unroll 1
   for (int g = 0; g < 4; g += 2) {
     Pixel s[2];
-    Material m[2];
     if (g != 0) {
-      alb[0] = s_stash[0][t];
-      alb[1] = s_stash[1][t];
-      mat[0] = s_stash[2][t];
-      mat[1] = s_stash[3][t];
-      dep[0] = __uint_as_float(s_stash[4][t]);
-      dep[1] = __uint_as_float(s_stash[5][t]);
-      nlo[0] = s_stash[6][t];
-      nhi[0] = s_stash[7][t];
-      nlo[1] = s_stash[8][t];
-      nhi[1] = s_stash[9][t];
+      mat[0] = s_stash[kRowMaterial + 2][t];
+      mat[1] = s_stash[kRowMaterial + 3][t];
+      dep[0] = dep4.z;
+      dep[1] = dep4.w;
+      nlo[0] = s_stash[kRowNormal + 0][t];
+      nhi[0] = s_stash[kRowNormal + 1][t];
+      nlo[1] = s_stash[kRowNormal + 2][t];
+      nhi[1] = s_stash[kRowNormal + 3][t];
+      cx[0] = cx_next[0];
+      cx[1] = cx_next[1];
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) setup_pixel(s[i], m[i], p, by_width, by_height, lx + g + i, y_full, dep[i], alb[i], mat[i], nlo[i], nhi[i]);
+    for (int i = 0; i < 2; ++i) setup_pixel(s[i], p, cx[i], cy, dep[i], mat[i], nlo[i], nhi[i]);
 
     // shades the first `count` records of s_light (count even, > 0)
     auto shade_list = [&](uint32_t count) {
@@ -504,13 +526,16 @@ __global__ __launch_bounds__(256, 4) void deferred_kernel(const DeferredParams p
         if (i < L) {
           lp = lights[3u * i];
           lc = lights[3u * i + 1u];
-          const float dx = fmaxf(fmaxf(box_lo[0] - lp.x, lp.x - box_hi[0]), 0.0f);
-          const float dy = fmaxf(fmaxf(box_lo[1] - lp.y, lp.y - box_hi[1]), 0.0f);
-          const float dz = fmaxf(fmaxf(box_lo[2] - lp.z, lp.z - box_hi[2]), 0.0f);
+          const float dx = fmaxf(fmaxf(s_tile[0] - lp.x, lp.x - s_tile[3]), 0.0f);
+          const float dy = fmaxf(fmaxf(s_tile[1] - lp.y, lp.y - s_tile[4]), 0.0f);
+          const float dz = fmaxf(fmaxf(s_tile[2] - lp.z, lp.z - s_tile[5]), 0.0f);
           hit = (dx * dx + dy * dy + dz * dz) < p.radius2;  // NaN position: never contributes, never listed
+          const float reach = s_tile[22];
 #pragma unroll
-          for (int c = 0; c < 4; ++c)  // outside a side face by more than the radius: cannot reach any pixel of the tile
-            hit = hit && !(((face[c][0] * lp.x + face[c][1] * lp.y) + face[c][2] * lp.z) + face[c][3] > reach);
+          for (int c = 0; c < 4; ++c) {  // outside a side face by more than the radius: cannot reach any pixel of the tile
+            const float* f = &s_tile[6 + 4 * c];
+            hit = hit && !(((f[0] * lp.x + f[1] * lp.y) + f[2] * lp.z) + f[3] > reach);
+          }
         }
         const uint64_t hits = __ballot(hit);
         __syncthreads();  // s_cnt and the list are free: every wave is past its previous use of them
@@ -547,12 +572,22 @@ __global__ __launch_bounds__(256, 4) void deferred_kernel(const DeferredParams p
       list_count = count;
       __syncthreads();  // everyone is done reading before the list is rebuilt (or reused)
     }
+    // results: the first pair's go to LDS (over the rows of the words just consumed) until the second
+    // pair is done, so that each lane writes its four pixels with full-width stores
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      finish_pixel(s[i], m[i], rgb[g + i]);
-      if (kOutMode == kOutRgba8)
-        packed[g + i] = quantize_unorm8(rgb[g + i][0]) | (quantize_unorm8(rgb[g + i][1]) << 8) |
-                        (quantize_unorm8(rgb[g + i][2]) << 16) | 0xFF000000u;
+      float rgb[3];
+      finish_pixel(s[i], s_stash[kRowAlbedo + g + i][t], s_stash[kRowMaterial + g + i][t], rgb);
+      if (kOutMode == kOutRgba8) {
+        s_stash[kRowAlbedo + g + i][t] = quantize_unorm8(rgb[0]) | (quantize_unorm8(rgb[1]) << 8) | (quantize_unorm8(rgb[2]) << 16) | 0xFF000000u;
+      } else if (g == 0) {
+        s_stash[kRowAlbedo + i][t] = __float_as_uint(rgb[0]);
+        s_stash[kRowMaterial + i][t] = __float_as_uint(rgb[1]);
+        s_stash[kRowExtra + i][t] = __float_as_uint(rgb[2]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) last[i][k] = rgb[k];
+      }
     }
   }
   if (!inside) return;
@@ -560,6 +595,9 @@ __global__ __launch_bounds__(256, 4) void deferred_kernel(const DeferredParams p
   const uint32_t valid = min(4u, p.width - x0);
   uint8_t* orow = p.out + (size_t)y * p.pitch_out;
   if (kOutMode == kOutRgba8) {
+    uint32_t packed[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) packed[i] = s_stash[kRowAlbedo + i][t];
     uint32_t* o = reinterpret_cast<uint32_t*>(orow) + x0;
     if (valid == 4u) {
       *reinterpret_cast<uint4*>(o) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
@@ -568,21 +606,32 @@ __global__ __launch_bounds__(256, 4) void deferred_kernel(const DeferredParams p
       for (int i = 0; i < 3; ++i)
         if ((uint32_t)i < valid) o[i] = packed[i];
     }
-  } else if (kOutMode == kOutRgba16f) {
-    uint2* o = reinterpret_cast<uint2*>(orow) + x0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if ((uint32_t)i < valid) {
-        const __half2 a = __floats2half2_rn(rgb[i][0], rgb[i][1]);
-        const __half2 b = __floats2half2_rn(rgb[i][2], 1.0f);
-        o[i] = make_uint2(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b));
-      }
-    }
   } else {
-    float4* o = reinterpret_cast<float4*>(orow) + x0;
+    float rgb[4][3];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if ((uint32_t)i < valid) o[i] = make_float4(rgb[i][0], rgb[i][1], rgb[i][2], 1.0f);
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int row = k == 0 ? kRowAlbedo : k == 1 ? kRowMaterial : kRowExtra;
+        rgb[i][k] = __uint_as_float(s_stash[row + i][t]);
+        rgb[2 + i][k] = last[i][k];
+      }
+    if (kOutMode == kOutRgba16f) {
+      uint2* o = reinterpret_cast<uint2*>(orow) + x0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if ((uint32_t)i < valid) {
+          const __half2 a = __floats2half2_rn(rgb[i][0], rgb[i][1]);
+          const __half2 b = __floats2half2_rn(rgb[i][2], 1.0f);
+          o[i] = make_uint2(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b));
+        }
+      }
+    } else {
+      float4* o = reinterpret_cast<float4*>(orow) + x0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if ((uint32_t)i < valid) o[i] = make_float4(rgb[i][0], rgb[i][1], rgb[i][2], 1.0f);
+    }
   }
 }
 
