@@ -41,6 +41,22 @@ def cull_algorithmic(n, visible, meshes):
     return n * 32.0 + visible * 4.0 + meshes * 20.0
 
 
+def profiled_traffic():
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc.json, newest
+    round): counters cannot be collected inside a timed run, so the figures come from the separate
+    --pmc runs of this same command (tools/profile_round.sh).  {} when no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    if not files:
+        return {}, None
+    try:
+        data = json.load(open(files[-1]))
+    except (OSError, ValueError):
+        return {}, None
+    out = {k: v["hbm_traffic_bytes_per_launch"] for k, v in data.items() if "hbm_traffic_bytes_per_launch" in v}
+    return out, os.path.relpath(files[-1], ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,6 +131,9 @@ def main():
     pixels_total = float(W) * H * K * world
     value = pixels_total / wall / 1e9
     dbytes, dflops = deferred_algorithmic(W, H, L)
+    pmc, pmc_file = profiled_traffic()
+    default_workload = (W, H, L, args.instances, args.meshes) == (3840, 2160, 256, 1 << 22, 1024)
+    d_traffic = pmc.get("deferred_kernel<0, false, false>") if default_workload else None
     ach_flops = dflops / (kern_ms * 1e-3)
     ach_bytes = dbytes / (kern_ms * 1e-3)
 
@@ -134,7 +153,8 @@ def main():
         "config": {"workload": f"deferred resolve {W}x{H}, {L} point lights, rgba8 output, one frame per GPU per step",
                    "width": W, "height": H, "lights": L, "parallelism": f"frame-batch x{world}", "device": info["name"]},
         "roofline": {"bound": "valu_fp32", "kernel": "deferred_kernel", "achieved": ach_flops / 1e12, "peak": VALU_FP32_PEAK / 1e12,
-                     "unit": "TFLOP/s", "frac": ach_flops / VALU_FP32_PEAK, "traffic": None,
+                     "unit": "TFLOP/s", "frac": ach_flops / VALU_FP32_PEAK, "traffic": d_traffic,
+                     "traffic_source": pmc_file if d_traffic is not None else None,
                      "kernel_ms": kern_ms, "algorithmic_flops": dflops, "algorithmic_bytes": dbytes,
                      "hbm_achieved_GBps": ach_bytes / 1e9, "hbm_frac": ach_bytes / HBM_PEAK},
     }
@@ -209,10 +229,12 @@ def main():
             call_ms = e1.elapsed_ms_since(e0) / K
             vis = int(css[0].results()["cmds"]["instanceCount"].sum())
             cb = cull_algorithmic(N, vis, M)
+            kernels = ("cull_init_cmds", "cull_atomic_kernel") if flags == 0 else ("cull_mask_kernel", "cull_scan_kernel", "cull_scatter_kernel")
+            c_traffic = sum(pmc[k] for k in kernels) if default_workload and all(k in pmc for k in kernels) else None
             cull[mode_name] = {"value": float(N) * K * world / cw / 1e9, "unit": "G instances/s", "ms_per_call": call_ms,
                                "visible_fraction": vis / N,
                                "roofline": {"bound": "hbm", "achieved": cb / (call_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
-                                            "unit": "GB/s", "frac": cb / (call_ms * 1e-3) / HBM_PEAK, "traffic": None,
+                                            "unit": "GB/s", "frac": cb / (call_ms * 1e-3) / HBM_PEAK, "traffic": c_traffic,
                                             "algorithmic_bytes": cb}}
         cull["config"] = {"workload": f"frustum cull + compaction, {N} instance AABBs, {M} meshes, {nsets} rotating input sets",
                           "parallelism": f"replicated scene x{world}"}
@@ -223,7 +245,7 @@ def main():
         import oracle  # checker/baseline only: never on the measured GPU path
         oracle.build()
         cores = min(16, os.cpu_count() or 1)
-        rows = max(8, H // 16)
+        rows = H  # the whole frame: about 70 core-seconds of the scalar restatement at 4K x 256
         tc0 = time.perf_counter()
         oracle.deferred(case["gbuf"], case["lights"], case["push"], mode="f32", rows=(0, rows), threads=cores, want=("rgba8",))
         tc = time.perf_counter() - tc0
