@@ -243,6 +243,188 @@ VKR_API int32_t vkr_mat4_inverse(const float m[16], float out_m[16]);
  * row3+row0, row3-row0, row3+row1, row3-row1, row2, row3-row2. */
 VKR_API void vkr_frustum_planes(const float view_proj[16], float out_planes[24]);
 
+/* ------------------------------------------------------------------ camera and per-frame constants
+ * CameraInputHandler of /root/reference/inc/vkcamera.hpp:9-67 without the GLFW types: the state
+ * (:62-63), getView (:51-53), the key movement of onKeyEvent (:30-47) and the mouse look of
+ * onCursorPosChange (:11-29). */
+typedef struct vkr_camera {
+  float pos[3];     /* default (0, 3, 71) */
+  float forward[3]; /* default (0, 0, -1) */
+  float up[3];      /* constant (0, -1, 0) */
+} vkr_camera;
+
+enum { VKR_KEY_W = 0, VKR_KEY_A = 1, VKR_KEY_S = 2, VKR_KEY_D = 3, VKR_KEY_SPACE = 4, VKR_KEY_LEFT_SHIFT = 5 };
+
+VKR_API void vkr_camera_default(vkr_camera* cam);
+/* lookAt(pos, pos + forward, up). */
+VKR_API void vkr_camera_view(const vkr_camera* cam, float out_view[16]);
+/* pos += dir * (0.2 * delta_time), negated for SPACE / A / S; dir = cross(forward, up) for A / D, up for
+ * SPACE / LEFT_SHIFT, forward for W / S.  delta_time is the reference's mDeltaTime (frame time in
+ * units of 10 ms).  Unknown keys are ignored. */
+VKR_API void vkr_camera_key(vkr_camera* cam, int32_t key, float delta_time);
+/* Mouse look by a cursor delta (pixels): 60 degrees per unit of delta, pitch clamped to
+ * [0.01 pi, 0.99 pi] from the up vector. */
+VKR_API void vkr_camera_cursor_delta(vkr_camera* cam, float dx, float dy);
+
+/* What the frame callback of /root/reference/src/main.cpp:206-209 computes before recording: view,
+ * vp = proj * view, inverse(vp), DeferredPushData {cameraPos, 1.0f, inverse(vp)}; plus the clip
+ * planes the cull pass takes. */
+typedef struct vkr_frame_constants {
+  float view[16];
+  float view_proj[16];
+  float inv_view_proj[16];
+  float planes[24];
+  float deferred_push[20];
+} vkr_frame_constants;
+/* VKR_ERR_INVALID_ARGUMENT if vp is singular. */
+VKR_API int32_t vkr_frame_setup(const vkr_camera* cam, const float proj[16], vkr_frame_constants* out);
+
+/* ------------------------------------------------------------------ light table source
+ * LightInfo of /root/reference/src/main.cpp:40-47 (= the std140 Light of deferred.comp:13-19). */
+typedef struct vkr_light_info {
+  float pos[3];
+  float opening_angle;  /* cos(radians(opening_angle) / 2) */
+  float color[3];       /* "intensity" */
+  float penumbra_angle; /* cos(radians(penumbra_angle) / 2) */
+  float dir[3];
+  float _temp;
+} vkr_light_info;
+
+/* The per-light arithmetic of /root/reference/src/main.cpp:57-69 over arrays of the JSON fields
+ * (angles in degrees). */
+VKR_API void vkr_pack_point_lights(uint32_t count, const float* pos3, const float* intensity3, const float* direction3,
+                                   const float* opening_angle_deg, const float* penumbra_angle_deg, vkr_light_info* out);
+/* Parses the text of a .fscene file (JSON) and packs every entry of "lights" whose "type" is
+ * "point_light" (/root/reference/src/main.cpp:48-70).  out may be null to count only.
+ * VKR_ERR_INVALID_ARGUMENT on malformed JSON or a point light missing a field the reference reads;
+ * VKR_ERR_OUT_OF_MEMORY if capacity is too small (out_count still holds the number found). */
+VKR_API int32_t vkr_fscene_point_lights(const char* json_text, uint64_t json_bytes, vkr_light_info* out, uint32_t capacity,
+                                        uint32_t* out_count);
+
+/* ------------------------------------------------------------------ scene tables
+ * What vw::Scene::Scene builds from an imported scene before any pass runs
+ * (/root/reference/src/vkmodel.cpp:55-134): the node tree flattened into per-mesh instance matrix
+ * lists (:55-73), then per kept mesh a MeshInfo, a template draw command, a PerMeshData and its
+ * contiguous run of model matrices (:89-111).  The description replaces the aiScene fields those
+ * lines read. */
+#define VKR_MESH_HAS_FACES 1u
+#define VKR_MESH_HAS_UV0 2u
+#define VKR_MESH_HAS_TRIANGLES 4u /* a mesh lacking any of the three is skipped (:91-93) */
+
+typedef struct vkr_scene_desc {
+  uint32_t node_count;              /* node 0 is the root */
+  const float* node_transform;      /* node_count x 16: aiMatrix4x4 a1..d4 (row-major), :61-65 */
+  const uint32_t* node_child_begin; /* node_count + 1 offsets into node_children */
+  const uint32_t* node_children;    /* child node indices, in aiNode::mChildren order */
+  const uint32_t* node_mesh_begin;  /* node_count + 1 offsets into node_meshes */
+  const uint32_t* node_meshes;      /* mesh indices (aiNode::mMeshes) */
+  uint32_t mesh_count;
+  const uint32_t* mesh_vertex_count; /* aiMesh::mNumVertices */
+  const uint32_t* mesh_face_count;   /* aiMesh::mNumFaces */
+  const uint32_t* mesh_material;     /* aiMesh::mMaterialIndex */
+  const uint32_t* mesh_flags;        /* VKR_MESH_* */
+} vkr_scene_desc;
+
+typedef struct vkr_scene_counts {
+  uint32_t kept_meshes;     /* meshes that pass :91-93 */
+  uint32_t kept_instances;  /* model matrices emitted (instances of kept meshes) */
+  uint32_t total_instances; /* mTotalInstanceCount: every node-mesh reference, kept or not (:68) */
+  uint32_t total_vertices;  /* mTotalVertexCount */
+  uint32_t total_indices;   /* mTotalIndexCount */
+} vkr_scene_counts;
+
+typedef struct vkr_mesh_info { /* vw::MeshInfo, /root/reference/inc/vkmodel.hpp:29-34 */
+  uint32_t indexCount, firstIndex, vertexOffset, materialIndex;
+} vkr_mesh_info;
+
+typedef struct vkr_per_mesh_data { /* /root/reference/inc/vkmodel.hpp:76-78 */
+  uint32_t materialIdx, modelMatrixBaseIndex;
+} vkr_per_mesh_data;
+
+typedef struct vkr_scene_tables { /* caller-allocated, sized from vkr_scene_counts */
+  vkr_mesh_info* mesh_info;                         /* kept_meshes */
+  vkr_draw_indexed_indirect_command* draw_commands; /* kept_meshes: {3*faces, #instances, firstIndex, vertexOffset, 0} */
+  vkr_per_mesh_data* per_mesh_data;                 /* kept_meshes */
+  float* mesh_matrices;                             /* kept_instances x 16, column-major */
+  uint32_t* mesh_base;                              /* kept_meshes + 1: modelMatrixBaseIndex per mesh, then the total */
+  uint32_t* vertex_base;                            /* kept_meshes + 1: vertexOffset per mesh, then the total */
+  uint32_t* source_mesh;                            /* kept_meshes: index of the mesh in the description */
+} vkr_scene_tables;
+
+VKR_API int32_t vkr_scene_count(const vkr_scene_desc* desc, vkr_scene_counts* out_counts);
+VKR_API int32_t vkr_scene_build_tables(const vkr_scene_desc* desc, const vkr_scene_counts* counts, vkr_scene_tables* out);
+
+/* Object-space bounds of every kept mesh: the min / max of computeAABB
+ * (/root/reference/src/vkmodel.cpp:166-171) over the mesh's vertices.  positions = the packed
+ * float3 position stream of the vertex buffer (:116), vertex_base as in vkr_scene_tables; mesh_aabb
+ * receives per mesh two float4 (min.xyz, 0) (max.xyz, 0).  A mesh without vertices gets
+ * (+inf, -inf).  All pointers are device memory. */
+VKR_API int32_t vkr_mesh_aabbs(vkr_context* ctx, const void* positions, const uint32_t* vertex_base, uint32_t mesh_count,
+                               void* mesh_aabb);
+/* World-space AABB of every instance, in the layout vkr_prep_indirect reads: the eight corners of the
+ * mesh's bounds in the order of /root/reference/src/vkmodel.cpp:172-173, each mapped by the
+ * instance's model matrix as ((m0*x + m1*y) + m2*z) + m3 per row in binary32 without fused
+ * multiply-add, then min / max.  aabb_min[i].w = mesh id of instance i.  All pointers device memory;
+ * mesh_matrices 16-byte aligned. */
+VKR_API int32_t vkr_instance_aabbs(vkr_context* ctx, const void* mesh_matrices, const uint32_t* mesh_base, const void* mesh_aabb,
+                                   uint32_t mesh_count, uint64_t instance_count, void* aabb_min, void* aabb_max);
+
+/* ------------------------------------------------------------------ G-buffer producers
+ * The four attachments the raster pass of /root/reference/src/main.cpp:111-129,214-219 fills and
+ * the deferred pass reads. */
+
+/* Attachment write conversions of /root/reference/shaders/offscreen.frag:13-16 into the formats of
+ * /root/reference/src/main.cpp:112-116: float4 -> R8G8B8A8_UNORM (NaN -> 0, clamp, round half to
+ * even), float4 -> R16G16B16A16_SFLOAT (round to nearest even), float -> D32_SFLOAT.  The four
+ * sources are device arrays of width x height float4 / float, rows contiguous. */
+typedef struct vkr_gbuffer_encode_args {
+  const void* albedo_f32;   /* float4 per pixel */
+  const void* material_f32; /* float4 per pixel */
+  const void* normal_f32;   /* float4 per pixel */
+  const void* depth_f32;    /* float per pixel */
+  vkr_image2d albedo, material, normal, depth; /* destinations */
+} vkr_gbuffer_encode_args;
+VKR_API int32_t vkr_gbuffer_encode(vkr_context* ctx, const vkr_gbuffer_encode_args* args);
+
+/* An analytic test scene (spheres over a checkered ground plane) written straight into the four
+ * attachments: per pixel the nearest hit along the camera ray through the pixel centre, depth =
+ * clip.z / clip.w of the hit under view_proj (1.0 where nothing is hit, the clear value of
+ * /root/reference/src/main.cpp:129), normal = minus the outward surface normal (the deferred pass
+ * negates it, /root/reference/shaders/deferred.comp:108), material = (occlusion, roughness,
+ * metalness, 1).  Not a rasteriser: it exists to give the deferred pass physically coherent inputs. */
+typedef struct vkr_sphere {
+  float center[3];
+  float radius;
+  float albedo[3];
+  float roughness;
+  float metalness;
+  float occlusion;
+  float pad[2];
+} vkr_sphere;
+
+typedef struct vkr_gbuffer_scene {
+  float view_proj[16];
+  float inv_view_proj[16];
+  float camera_pos[3];
+  uint32_t sphere_count;
+  float ground_plane[4];    /* n.xyz, d: points with dot(n, p) + d = 0; n = 0 disables the ground */
+  float ground_albedo_a[3]; /* checker colours */
+  float ground_tile;        /* checker edge length (world units), > 0 */
+  float ground_albedo_b[3];
+  float ground_roughness;
+  float ground_metalness;
+  float pad[3];
+} vkr_gbuffer_scene;
+
+typedef struct vkr_gbuffer_fill_args {
+  vkr_image2d albedo, material, normal, depth; /* destinations */
+  const void* spheres;                         /* device: scene.sphere_count x vkr_sphere */
+  vkr_gbuffer_scene scene;
+  uint32_t row_offset;  /* the images hold rows [row_offset, row_offset + height) of a frame */
+  uint32_t full_height; /* full_height rows tall; 0 / 0 = whole frame */
+} vkr_gbuffer_fill_args;
+VKR_API int32_t vkr_gbuffer_fill(vkr_context* ctx, const vkr_gbuffer_fill_args* args);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

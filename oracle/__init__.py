@@ -26,7 +26,7 @@ _lib = None
 
 def build(force: bool = False) -> str:
     """Compile liboracle.so with gcc (see Makefile)."""
-    srcs = [os.path.join(_HERE, f) for f in ("deferred_oracle.c", "cull_oracle.c", "deferred_oracle_body.inc", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("deferred_oracle.c", "cull_oracle.c", "scene_oracle.c", "deferred_oracle_body.inc", "Makefile")]
     stale = force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
     if stale:
@@ -58,8 +58,7 @@ class CullArgs(C.Structure):
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            build()
+        build()  # no-op when liboracle.so is newer than its sources
         _lib = C.CDLL(_LIB_PATH)
         for name in ("oracle_deferred_f32", "oracle_deferred_f64", "oracle_deferred_mix"):
             fn = getattr(_lib, name)
@@ -234,3 +233,165 @@ def frustum_planes(vp: np.ndarray) -> np.ndarray:
     row = [M[:, r].copy() for r in range(4)]
     return np.stack([row[3] + row[0], row[3] - row[0], row[3] + row[1], row[3] - row[1],
                      row[2], row[3] - row[2]]).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------
+# Callers either side of the passes (scene_oracle.c): scene tables, bounds, camera, light
+# records, attachment encodes, analytic G-buffer fill.
+# ---------------------------------------------------------------------------------------------
+
+class _Scene(C.Structure):
+    _fields_ = [("node_count", C.c_uint32), ("node_transform", C.c_void_p), ("node_child_begin", C.c_void_p),
+                ("node_children", C.c_void_p), ("node_mesh_begin", C.c_void_p), ("node_meshes", C.c_void_p),
+                ("mesh_count", C.c_uint32), ("mesh_vertex_count", C.c_void_p), ("mesh_face_count", C.c_void_p),
+                ("mesh_material", C.c_void_p), ("mesh_valid", C.c_void_p)]
+
+
+def scene_tables(nodes, meshes) -> dict:
+    """nodes: [(a1..d4 row-major 4x4, [children], [meshes])], node 0 = root; meshes: [(vertices, faces,
+    material, valid)].  Returns what vw::Scene::Scene builds (vkmodel.cpp:55-111)."""
+    L = lib()
+    nt = np.ascontiguousarray([np.asarray(n[0], np.float32).reshape(16) for n in nodes], np.float32)
+    cb, ch, mb, nm = [0], [], [0], []
+    for _, c_, m_ in nodes:
+        ch += list(c_)
+        cb.append(len(ch))
+        nm += list(m_)
+        mb.append(len(nm))
+    cb, ch, mb, nm = (np.asarray(a, np.uint32) for a in (cb, ch, mb, nm))
+    ms = np.asarray(meshes, np.uint32).reshape(-1, 4)
+    cols = [np.ascontiguousarray(ms[:, k]) for k in range(4)]
+    s = _Scene(len(nodes), _ptr(nt), _ptr(cb), _ptr(ch), _ptr(mb), _ptr(nm), ms.shape[0], *(_ptr(c_) for c_ in cols))
+    pairs_mesh = np.zeros(max(len(nm), 1), np.uint32)
+    pairs_mat = np.zeros((max(len(nm), 1), 16), np.float32)
+    L.oracle_scene_flatten.restype = C.c_uint32
+    L.oracle_scene_flatten.argtypes = [C.POINTER(_Scene), C.c_void_p, C.c_void_p]
+    n = L.oracle_scene_flatten(C.byref(s), _ptr(pairs_mesh), _ptr(pairs_mat))
+    M = ms.shape[0]
+    mesh_info = np.zeros((M, 4), np.uint32)
+    draw = np.zeros((M, 5), np.uint32)
+    per_mesh = np.zeros((M, 2), np.uint32)
+    mats = np.zeros((max(n, 1), 16), np.float32)
+    mesh_base = np.zeros(M + 1, np.uint32)
+    vertex_base = np.zeros(M + 1, np.uint32)
+    source = np.zeros(M, np.uint32)
+    totals = np.zeros(3, np.uint32)
+    L.oracle_scene_tables.restype = C.c_uint32
+    L.oracle_scene_tables.argtypes = [C.POINTER(_Scene)] + [C.c_void_p] * 2 + [C.c_uint32] + [C.c_void_p] * 8
+    k = L.oracle_scene_tables(C.byref(s), _ptr(pairs_mesh), _ptr(pairs_mat), n, _ptr(mesh_info), _ptr(draw), _ptr(per_mesh), _ptr(mats),
+                              _ptr(mesh_base), _ptr(vertex_base), _ptr(source), _ptr(totals))
+    return {"pairs_mesh": pairs_mesh[:n], "pairs_matrix": pairs_mat[:n], "total_instances": int(n), "kept_meshes": int(k),
+            "mesh_info": mesh_info[:k], "draw_commands": draw[:k].copy().view(DRAW_CMD_DTYPE).reshape(-1), "per_mesh_data": per_mesh[:k],
+            "mesh_matrices": mats[:int(totals[2])], "mesh_base": mesh_base[:k + 1], "vertex_base": vertex_base[:k + 1],
+            "source_mesh": source[:k], "totals": totals}
+
+
+def mesh_aabbs(positions: np.ndarray, vertex_base: np.ndarray) -> np.ndarray:
+    positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+    vertex_base = np.ascontiguousarray(vertex_base, np.uint32)
+    m = vertex_base.shape[0] - 1
+    out = np.zeros((m, 8), np.float32)
+    fn = lib().oracle_mesh_aabbs
+    fn.restype, fn.argtypes = None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    fn(_ptr(positions), _ptr(vertex_base), m, _ptr(out))
+    return out
+
+
+def instance_aabbs(matrices: np.ndarray, mesh_base: np.ndarray, mesh_aabb: np.ndarray):
+    matrices = np.ascontiguousarray(matrices, np.float32).reshape(-1, 16)
+    mesh_base = np.ascontiguousarray(mesh_base, np.uint32)
+    mesh_aabb = np.ascontiguousarray(mesh_aabb, np.float32).reshape(-1, 8)
+    n = matrices.shape[0]
+    mn, mx = np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)
+    fn = lib().oracle_instance_aabbs
+    fn.restype, fn.argtypes = None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    fn(_ptr(matrices), _ptr(mesh_base), _ptr(mesh_aabb), mesh_base.shape[0] - 1, _ptr(mn), _ptr(mx))
+    return mn, mx
+
+
+class Camera(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("forward", C.c_float * 3), ("up", C.c_float * 3)]
+
+    @staticmethod
+    def default() -> "Camera":
+        c = Camera()
+        lib().oracle_camera_default(C.byref(c))
+        return c
+
+    def view(self) -> np.ndarray:
+        m = np.zeros(16, np.float32)
+        lib().oracle_camera_view(C.byref(self), _ptr(m))
+        return m
+
+    def key(self, key: int, dt: float):
+        fn = lib().oracle_camera_key
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_float]
+        fn(C.byref(self), key, dt)
+
+    def cursor_delta(self, dx: float, dy: float):
+        fn = lib().oracle_camera_cursor_delta
+        fn.argtypes = [C.c_void_p, C.c_float, C.c_float]
+        fn(C.byref(self), dx, dy)
+
+    def state(self) -> np.ndarray:
+        return np.array(list(self.pos) + list(self.forward) + list(self.up), np.float32)
+
+
+def pack_point_lights(pos, intensity, direction, opening_deg, penumbra_deg) -> np.ndarray:
+    pos, intensity, direction = (np.ascontiguousarray(a, np.float32).reshape(-1, 3) for a in (pos, intensity, direction))
+    oa, pa = (np.ascontiguousarray(a, np.float32).reshape(-1) for a in (opening_deg, penumbra_deg))
+    out = np.zeros((pos.shape[0], 12), np.float32)
+    fn = lib().oracle_pack_point_lights
+    fn.restype, fn.argtypes = None, [C.c_uint32] + [C.c_void_p] * 6
+    fn(pos.shape[0], _ptr(pos), _ptr(intensity), _ptr(direction), _ptr(oa), _ptr(pa), _ptr(out))
+    return out
+
+
+def fscene_point_lights(text: str) -> np.ndarray:
+    """main.cpp:48-70 with Python's json in the place of nlohmann::json: doubles narrowed to float."""
+    import json
+    scene = json.loads(text)
+    pts = [l for l in scene.get("lights", []) if l.get("type") == "point_light"]
+    if not pts:
+        return np.zeros((0, 12), np.float32)
+    f32 = lambda key, n: np.array([[np.float32(l[key][i]) for i in range(n)] for l in pts], np.float32)
+    oa = np.array([np.float32(l["opening_angle"]) for l in pts], np.float32)
+    pa = np.array([np.float32(l["penumbra_angle"]) for l in pts], np.float32)
+    return pack_point_lights(f32("pos", 3), f32("intensity", 3), f32("direction", 3), oa, pa)
+
+
+def gbuffer_encode(albedo, material, normal, depth) -> dict:
+    """float planes (H,W,4)/(H,W) -> the four attachment formats."""
+    albedo, material, normal = (np.ascontiguousarray(a, np.float32) for a in (albedo, material, normal))
+    depth = np.ascontiguousarray(depth, np.float32)
+    H, W = depth.shape
+    out = {"albedo": np.zeros((H, W, 4), np.uint8), "material": np.zeros((H, W, 4), np.uint8),
+           "normal": np.zeros((H, W, 4), np.uint16), "depth": np.zeros((H, W), np.float32)}
+    fn = lib().oracle_gbuffer_encode
+    fn.restype, fn.argtypes = None, [C.c_void_p] * 4 + [C.c_uint64] + [C.c_void_p] * 4
+    fn(_ptr(albedo), _ptr(material), _ptr(normal), _ptr(depth), H * W, _ptr(out["albedo"]), _ptr(out["material"]), _ptr(out["normal"]), _ptr(out["depth"]))
+    out["normal"] = out["normal"].view(np.float16)
+    return out
+
+
+class GBufferScene(C.Structure):
+    _fields_ = [("view_proj", C.c_float * 16), ("inv_view_proj", C.c_float * 16), ("camera_pos", C.c_float * 3),
+                ("sphere_count", C.c_uint32), ("ground_plane", C.c_float * 4), ("ground_albedo_a", C.c_float * 3),
+                ("ground_tile", C.c_float), ("ground_albedo_b", C.c_float * 3), ("ground_roughness", C.c_float),
+                ("ground_metalness", C.c_float), ("pad", C.c_float * 3)]
+
+
+def gbuffer_fill(scene_bytes: bytes, spheres: np.ndarray, width: int, height: int, rows=None) -> dict:
+    """scene_bytes: the 208-byte scene block (same layout as the product's vkr_gbuffer_scene)."""
+    sc = GBufferScene.from_buffer_copy(scene_bytes)
+    spheres = np.ascontiguousarray(spheres).view(np.uint8).reshape(-1)
+    y0, y1 = rows if rows is not None else (0, height)
+    h = y1 - y0
+    out = {"albedo": np.zeros((h, width, 4), np.uint8), "material": np.zeros((h, width, 4), np.uint8),
+           "normal": np.zeros((h, width, 4), np.uint16), "depth": np.zeros((h, width), np.float32)}
+    fn = lib().oracle_gbuffer_fill
+    fn.restype, fn.argtypes = None, [C.c_void_p, C.c_void_p] + [C.c_uint32] * 4 + [C.c_void_p] * 4
+    fn(C.byref(sc), _ptr(spheres) if spheres.size else None, width, h, y0, height, _ptr(out["albedo"]), _ptr(out["material"]),
+       _ptr(out["normal"]), _ptr(out["depth"]))
+    out["normal"] = out["normal"].view(np.float16)
+    return out

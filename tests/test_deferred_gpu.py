@@ -201,3 +201,69 @@ def test_argument_errors(vkr, synth, ctx):
     a.flags = 0x80
     with pytest.raises(vkr.VkrError, match="flags"):
         ctx.deferred_resolve(a)
+
+
+@pytest.mark.parametrize("radius", [None, 1000.0, 30.0])
+def test_not_a_number_pixels(vkr, synth, oracle, ctx, radius):
+    """Cleared texels (normal 0 -> normalize(0)), NaN / Inf normals and depths: NaN wherever the reference
+    arithmetic yields NaN (stored as 0 in rgba8), the ambient colour where no light takes part."""
+    w, h, L = 64, 24, 9
+    case = synth.deferred_case(w, h, L, config_index=11)
+    g = {k: v.copy() for k, v in case["gbuf"].items()}
+    g["normal"][2, 5:9, :3] = 0.0                      # cleared attachment (main.cpp:128)
+    g["normal"][3, 7, 0] = np.float16(np.nan)
+    g["normal"][4, 8, 1] = np.float16(np.inf)
+    g["depth"][5, 9] = np.nan
+    g["depth"][6, 10] = np.inf
+    g["normal"][7, 40:44, :3] = 0.0
+    g["albedo"][7, 40:44, :3] = 200                    # nonzero albedo: ambient alone would be visible
+    case = dict(case, gbuf=g)
+    flags = 0
+    if radius:
+        push = case["push"].copy()
+        push[3] = radius
+        case["push"] = push
+        flags = vkr.DEFERRED_RADIUS_CUTOFF
+    ref = oracle.deferred(g, case["lights"], case["push"], mode="mix", radius_cutoff=bool(radius), want=("f64", "rgba8"))
+    got, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT, flags=flags)
+    ref_nan = np.isnan(ref["f64"][..., :3]).any(-1)
+    got_nan = np.isnan(got[..., :3]).any(-1)
+    if radius != 30.0:  # every light takes part: the oracle agrees these are NaN (with a short radius only where one is near)
+        assert ref_nan[2, 5:9].all() and ref_nan[3, 7] and ref_nan[7, 40:44].all()
+    assert np.array_equal(got_nan, ref_nan)
+    assert np.isnan(got[ref_nan][:, :3]).all()                             # all three channels
+    assert_color_close(got[..., :3], ref["f64"][..., :3], ref["near_threshold"].astype(bool) | ref_nan, "finite pixels")
+    got8, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R8G8B8A8_UNORM, flags=flags)
+    assert (got8[ref_nan][:, :3] == 0).all() and (got8[..., 3] == 255).all()
+    assert np.abs(got8.astype(int) - ref["rgba8"].astype(int)).max() <= 1
+    # without lights nothing is evaluated on the normal: the ambient colour survives
+    case0 = dict(case, lights=np.zeros((0, 12), np.float32))
+    got0, _ = run_deferred_gpu(vkr, ctx, case0, vkr.FORMAT_R32G32B32A32_SFLOAT, flags=flags)
+    assert np.isfinite(got0).all() and np.allclose(got0[7, 40:44, :3], 0.05 * 200 / 255, rtol=1e-6)
+
+
+def test_non_finite_lights(vkr, synth, oracle, ctx):
+    """Light records with NaN / Inf positions: NaN exactly where the restated arithmetic (min / max as
+    minNum / maxNum; GLSL leaves them undefined for NaN operands) yields NaN, i.e. on the pixels that face
+    the viewer; back-facing pixels take the early-out and stay finite."""
+    w, h, L = 48, 20, 6
+    case = synth.deferred_case(w, h, L, config_index=12)
+    good = case["lights"].copy().reshape(-1, 12)
+    extra = np.zeros((3, 12), np.float32)
+    extra[0, 0:3], extra[0, 4:7] = (np.nan, 0, 0), (5, 5, 5)
+    extra[1, 0:3], extra[1, 4:7] = (np.inf, 1, 2), (5, 5, 5)
+    extra[2, 0:3], extra[2, 4:7] = (1, -np.inf, 2), (5, 5, 5)
+    for bad in (extra[:1], extra[1:2], extra[2:], extra):
+        lights = np.concatenate([good[:3], bad, good[3:]])
+        got, _ = run_deferred_gpu(vkr, ctx, dict(case, lights=lights), vkr.FORMAT_R32G32B32A32_SFLOAT)
+        ref = oracle.deferred(case["gbuf"], lights, case["push"], mode="mix", want=("f64", "rgba8"))
+        ref_nan = np.isnan(ref["f64"][..., :3]).any(-1)
+        near = ref["near_threshold"].astype(bool)
+        got_nan = np.isnan(got[..., :3]).any(-1)
+        assert 0.5 < ref_nan.mean() < 1.0
+        assert np.array_equal(got_nan | near, ref_nan | near)
+        assert_color_close(got[..., :3], ref["f64"][..., :3], near | ref_nan, "pixels the bad light does not reach")
+        got8, _ = run_deferred_gpu(vkr, ctx, dict(case, lights=lights), vkr.FORMAT_R8G8B8A8_UNORM)
+        d = np.abs(got8.astype(int) - ref["rgba8"].astype(int))
+        d[near] = 0
+        assert d.max() <= 1 and (got8[ref_nan & ~near][:, :3] == 0).all()

@@ -64,6 +64,62 @@ class CullArgs(C.Structure):
                 ("error_flag", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64)]
 
 
+class Camera(C.Structure):
+    """vkr_camera: CameraInputHandler state of /root/reference/inc/vkcamera.hpp:62-63."""
+    _fields_ = [("pos", C.c_float * 3), ("forward", C.c_float * 3), ("up", C.c_float * 3)]
+
+
+class FrameConstants(C.Structure):
+    _fields_ = [("view", C.c_float * 16), ("view_proj", C.c_float * 16), ("inv_view_proj", C.c_float * 16),
+                ("planes", C.c_float * 24), ("deferred_push", C.c_float * 20)]
+
+
+LIGHT_INFO_DTYPE = np.dtype([("pos", "<f4", 3), ("opening_angle", "<f4"), ("color", "<f4", 3), ("penumbra_angle", "<f4"),
+                             ("dir", "<f4", 3), ("_temp", "<f4")])
+assert LIGHT_INFO_DTYPE.itemsize == LIGHT_STRIDE
+MESH_INFO_DTYPE = np.dtype([("indexCount", "<u4"), ("firstIndex", "<u4"), ("vertexOffset", "<u4"), ("materialIndex", "<u4")])
+PER_MESH_DATA_DTYPE = np.dtype([("materialIdx", "<u4"), ("modelMatrixBaseIndex", "<u4")])
+SPHERE_DTYPE = np.dtype([("center", "<f4", 3), ("radius", "<f4"), ("albedo", "<f4", 3), ("roughness", "<f4"),
+                         ("metalness", "<f4"), ("occlusion", "<f4"), ("pad", "<f4", 2)])
+assert SPHERE_DTYPE.itemsize == 48
+MESH_HAS_FACES, MESH_HAS_UV0, MESH_HAS_TRIANGLES = 1, 2, 4
+KEY_W, KEY_A, KEY_S, KEY_D, KEY_SPACE, KEY_LEFT_SHIFT = range(6)
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("node_count", C.c_uint32), ("node_transform", C.c_void_p), ("node_child_begin", C.c_void_p),
+                ("node_children", C.c_void_p), ("node_mesh_begin", C.c_void_p), ("node_meshes", C.c_void_p),
+                ("mesh_count", C.c_uint32), ("mesh_vertex_count", C.c_void_p), ("mesh_face_count", C.c_void_p),
+                ("mesh_material", C.c_void_p), ("mesh_flags", C.c_void_p)]
+
+
+class SceneCounts(C.Structure):
+    _fields_ = [("kept_meshes", C.c_uint32), ("kept_instances", C.c_uint32), ("total_instances", C.c_uint32),
+                ("total_vertices", C.c_uint32), ("total_indices", C.c_uint32)]
+
+
+class SceneTables(C.Structure):
+    _fields_ = [("mesh_info", C.c_void_p), ("draw_commands", C.c_void_p), ("per_mesh_data", C.c_void_p),
+                ("mesh_matrices", C.c_void_p), ("mesh_base", C.c_void_p), ("vertex_base", C.c_void_p), ("source_mesh", C.c_void_p)]
+
+
+class GBufferEncodeArgs(C.Structure):
+    _fields_ = [("albedo_f32", C.c_void_p), ("material_f32", C.c_void_p), ("normal_f32", C.c_void_p), ("depth_f32", C.c_void_p),
+                ("albedo", Image2D), ("material", Image2D), ("normal", Image2D), ("depth", Image2D)]
+
+
+class GBufferScene(C.Structure):
+    _fields_ = [("view_proj", C.c_float * 16), ("inv_view_proj", C.c_float * 16), ("camera_pos", C.c_float * 3),
+                ("sphere_count", C.c_uint32), ("ground_plane", C.c_float * 4), ("ground_albedo_a", C.c_float * 3),
+                ("ground_tile", C.c_float), ("ground_albedo_b", C.c_float * 3), ("ground_roughness", C.c_float),
+                ("ground_metalness", C.c_float), ("pad", C.c_float * 3)]
+
+
+class GBufferFillArgs(C.Structure):
+    _fields_ = [("albedo", Image2D), ("material", Image2D), ("normal", Image2D), ("depth", Image2D),
+                ("spheres", C.c_void_p), ("scene", GBufferScene), ("row_offset", C.c_uint32), ("full_height", C.c_uint32)]
+
+
 # Every symbol include/vkr_c.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 _PP = C.POINTER(C.c_void_p)
@@ -108,6 +164,19 @@ EXPORTS = {
     "vkr_mat4_mul": (None, [_P, _P, _P]),
     "vkr_mat4_inverse": (C.c_int32, [_P, _P]),
     "vkr_frustum_planes": (None, [_P, _P]),
+    "vkr_camera_default": (None, [C.POINTER(Camera)]),
+    "vkr_camera_view": (None, [C.POINTER(Camera), _P]),
+    "vkr_camera_key": (None, [C.POINTER(Camera), C.c_int32, C.c_float]),
+    "vkr_camera_cursor_delta": (None, [C.POINTER(Camera), C.c_float, C.c_float]),
+    "vkr_frame_setup": (C.c_int32, [C.POINTER(Camera), _P, C.POINTER(FrameConstants)]),
+    "vkr_pack_point_lights": (None, [C.c_uint32, _P, _P, _P, _P, _P, _P]),
+    "vkr_fscene_point_lights": (C.c_int32, [C.c_char_p, C.c_uint64, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "vkr_scene_count": (C.c_int32, [C.POINTER(SceneDesc), C.POINTER(SceneCounts)]),
+    "vkr_scene_build_tables": (C.c_int32, [C.POINTER(SceneDesc), C.POINTER(SceneCounts), C.POINTER(SceneTables)]),
+    "vkr_mesh_aabbs": (C.c_int32, [_P, _P, _P, C.c_uint32, _P]),
+    "vkr_instance_aabbs": (C.c_int32, [_P, _P, _P, _P, C.c_uint32, C.c_uint64, _P, _P]),
+    "vkr_gbuffer_encode": (C.c_int32, [_P, C.POINTER(GBufferEncodeArgs)]),
+    "vkr_gbuffer_fill": (C.c_int32, [_P, C.POINTER(GBufferFillArgs)]),
 }
 
 _lib = None

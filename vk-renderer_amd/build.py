@@ -22,7 +22,10 @@ UNITS = [
     # -falign-loops=32: the light loop's header on a 32-byte fetch boundary (measured: up to 10 % between placements).
     ("deferred.hip", ["-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-falign-loops=32"]),
     ("cull.hip", ["-O3", "-ffp-contract=off"]),
+    ("scene.hip", ["-O3", "-ffp-contract=off"]),
+    ("gbuffer.hip", ["-O3", "-ffp-contract=off"]),
     ("vkr_api.hip", ["-O2"]),
+    ("vkr_host.hip", ["-O2", "-ffp-contract=off"]),
 ]
 
 

@@ -110,6 +110,7 @@ struct Pixel {
   float a2, rh, ebm1, pv;      // alpha^2, roughness/2, energyBias-1, (1-vn)^5
   // accumulators: 1e-7 * sum_j color_j * {diffuse, spec, spec*(1-v.h)^5} scalar weights
   float ad[3], as0[3], as1[3];
+  float in_range;              // radius cutoff only: > 0 once any light lay inside the radius
 };
 
 struct Light {
@@ -172,7 +173,12 @@ __device__ __forceinline__ void shade4(Pixel& a, Pixel& b, const Light& A, const
     // early-out of deferred.comp:43,84 as a multiplier: (c - 1e-6) * 2^100 is exact inside the FMA; its clamp
     // is 1 for every c > 1e-6 and 0 for c <= 1e-6 or NaN
     float ci = (c[k] * clamp01_(fma_(c[k], kc.step_scale, kc.step_bias))) * att[k];
-    if (kRadius) ci *= clamp01_(fma_(dll[k], -kRadiusStepScale, kc.radius2_scaled));  // 1 iff dist^2 < radius^2
+    if (kRadius) {
+      const float near = clamp01_(fma_(dll[k], -kRadiusStepScale, kc.radius2_scaled));  // 1 iff dist^2 < radius^2
+      ci *= near;
+      Pixel& s = (k & 1) ? b : a;
+      s.in_range += near;
+    }
     const float ks0 = (hh[k] * hh[k]) * rden[k];
     wd[k] = kd[k] * ci;
     ws[k] = ks0 * ci;
@@ -256,14 +262,20 @@ __device__ __forceinline__ void setup_pixel(Pixel& s, const DeferredParams& p, f
   s.pv = pow5_(clamp01_(1.0f - s.vn));
 #pragma unroll
   for (int k = 0; k < 3; ++k) s.ad[k] = s.as0[k] = s.as1[k] = 0.0f;
+  s.in_range = 0.0f;
 }
 
 // Combines the three light sums into the pixel colour (deferred.comp:107,114-115,127-128).  The
 // albedo and material words are decoded here, after the light loop, so that nothing of them occupies
 // registers during it.
-__device__ __forceinline__ void finish_pixel(const Pixel& s, uint32_t albedo, uint32_t material, float out[3]) {
+// `lit_by_any`: at least one light took part for this pixel (any light at all, or with the radius
+// cutoff one inside the radius).  A pixel whose normal or position is not a number (a cleared G-buffer
+// texel has normal 0: normalize(0)) then comes out NaN, as every term of deferred.comp:120-129 does
+// (rgba8 stores it as 0); with no light taking part it keeps its ambient colour.
+__device__ __forceinline__ void finish_pixel(const Pixel& s, uint32_t albedo, uint32_t material, bool lit_by_any, float out[3]) {
   const float rough = unorm8(material, 1), metal = unorm8(material, 2);
   const bool front = s.vn > kEarlyOut;  // deferred.comp:43,84 (vDotN half of the early-out)
+  const float unlit = (lit_by_any && !(s.vn == s.vn)) ? __builtin_nanf("") : 0.0f;
   const float ef = fma_(const_inv151(), rough, 1.0f - rough);  // mix(1, 1/1.51, r)
   const float kdiff = (kPi * kInvDistFloor) * ef;  // the light sums carry a factor 1e-7
   const float kspec = (s.a2 * kInvDistFloor) * rcp_(kPi * (s.vn + sqrt_(fma_(s.a2, s.vn * s.vn, 1.0f))));
@@ -273,7 +285,7 @@ __device__ __forceinline__ void finish_pixel(const Pixel& s, uint32_t albedo, ui
     const float cd = alb * (1.0f - metal);  // mix(albedo, 0, metal)
     const float cs = alb * metal;           // mix(0, albedo, metal)
     const float lit = fma_(cd * kdiff, s.ad[k], kspec * fma_(cs, s.as0[k], (1.0f - cs) * s.as1[k]));
-    out[k] = fma_(kAmbient, alb, front ? lit : 0.0f);
+    out[k] = fma_(kAmbient, alb, front ? lit : unlit);
   }
 }
 
@@ -577,7 +589,7 @@ __global__ __launch_bounds__(256, 4) void deferred_kernel(const DeferredParams p
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       float rgb[3];
-      finish_pixel(s[i], s_stash[kRowAlbedo + g + i][t], s_stash[kRowMaterial + g + i][t], rgb);
+      finish_pixel(s[i], s_stash[kRowAlbedo + g + i][t], s_stash[kRowMaterial + g + i][t], kRadius ? s[i].in_range > 0.0f : L > 0u, rgb);
       if (kOutMode == kOutRgba8) {
         s_stash[kRowAlbedo + g + i][t] = quantize_unorm8(rgb[0]) | (quantize_unorm8(rgb[1]) << 8) | (quantize_unorm8(rgb[2]) << 16) | 0xFF000000u;
       } else if (g == 0) {

@@ -1,0 +1,314 @@
+// Producers of the four G-buffer attachments the deferred pass reads
+// (/root/reference/src/main.cpp:111-117: albedo rgba8, material rgba8, normal rgba16f, depth d32f).
+//   encode: the attachment write conversions of /root/reference/shaders/offscreen.frag:13-16 applied
+//           to float planes (what the ROPs do in the reference's raster pass);
+//   fill:   an analytic scene (spheres over a checkered plane) ray-cast per pixel and written in those
+//           formats - test and bench input with coherent depth / normals, not a rasteriser.
+// Both are write-bound streams (20 bytes per pixel).  Contraction is off for this file and every
+// division / square root is the correctly rounded one, so the bytes written equal those of a binary32
+// CPU evaluation of the same expressions (sqrtf, not __fsqrt_rn: the latter is the approximate native square root).
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vkr_c.h"
+#include "vkr_internal.h"
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 load_stream(const float4* p) {
+  const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void store_stream(float4* p, float4 v) {
+  v4f t;
+  t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+  __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
+}
+
+__device__ __forceinline__ uint32_t unorm8(float c) {
+  // NaN -> 0, clamp to [0,1], scale, round half to even (Vulkan float -> UNORM conversion)
+  const float t = (c > 0.0f) ? (c < 1.0f ? c : 1.0f) : 0.0f;
+  return (uint32_t)__builtin_rintf(t * 255.0f);
+}
+__device__ __forceinline__ uint32_t pack_unorm8x4(float r, float g, float b, float a) {
+  return unorm8(r) | (unorm8(g) << 8) | (unorm8(b) << 16) | (unorm8(a) << 24);
+}
+__device__ __forceinline__ uint2 pack_half4(float x, float y, float z, float w) {
+  const __half2 lo = __floats2half2_rn(x, y), hi = __floats2half2_rn(z, w);
+  return make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
+}
+
+struct Planes {
+  uint8_t *albedo, *material, *normal, *depth;
+  uint32_t pitch_albedo, pitch_material, pitch_normal, pitch_depth;
+  uint32_t width, height;
+};
+
+// ---------------------------------------------------------------- encode: one lane = four pixels of a row
+__global__ __launch_bounds__(256) void gbuffer_encode_kernel(const float4* __restrict__ albedo, const float4* __restrict__ material,
+                                                             const float4* __restrict__ normal, const float* __restrict__ depth, Planes o) {
+  const uint32_t x0 = (blockIdx.x * 64u + (threadIdx.x & 63u)) * 4u;
+  const uint32_t y = blockIdx.y * 4u + (threadIdx.x >> 6);
+  if (x0 >= o.width || y >= o.height) return;
+  const uint32_t n = min(4u, o.width - x0);
+  const size_t base = (size_t)y * o.width + x0;
+  uint32_t a[4], m[4];
+  uint2 nn[4];
+  float d[4];
+#pragma unroll
+  for (uint32_t i = 0; i < 4u; ++i) {
+    const size_t p = base + (i < n ? i : 0u);
+    const float4 av = load_stream(albedo + p), mv = load_stream(material + p), nv = load_stream(normal + p);
+    a[i] = pack_unorm8x4(av.x, av.y, av.z, av.w);
+    m[i] = pack_unorm8x4(mv.x, mv.y, mv.z, mv.w);
+    nn[i] = pack_half4(nv.x, nv.y, nv.z, nv.w);
+    d[i] = __builtin_nontemporal_load(depth + p);
+  }
+  uint32_t* pa = reinterpret_cast<uint32_t*>(o.albedo + (size_t)y * o.pitch_albedo) + x0;
+  uint32_t* pm = reinterpret_cast<uint32_t*>(o.material + (size_t)y * o.pitch_material) + x0;
+  uint2* pn = reinterpret_cast<uint2*>(o.normal + (size_t)y * o.pitch_normal) + x0;
+  float* pd = reinterpret_cast<float*>(o.depth + (size_t)y * o.pitch_depth) + x0;
+  if (n == 4u) {
+    *reinterpret_cast<uint4*>(pa) = make_uint4(a[0], a[1], a[2], a[3]);
+    *reinterpret_cast<uint4*>(pm) = make_uint4(m[0], m[1], m[2], m[3]);
+    *reinterpret_cast<uint4*>(pn) = make_uint4(nn[0].x, nn[0].y, nn[1].x, nn[1].y);
+    *reinterpret_cast<uint4*>(pn + 2) = make_uint4(nn[2].x, nn[2].y, nn[3].x, nn[3].y);
+    *reinterpret_cast<float4*>(pd) = make_float4(d[0], d[1], d[2], d[3]);
+  } else {
+    for (uint32_t i = 0; i < n; ++i) {
+      pa[i] = a[i];
+      pm[i] = m[i];
+      pn[i] = nn[i];
+      pd[i] = d[i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------- fill
+struct FillParams {
+  Planes o;
+  const vkr_sphere* spheres;
+  uint32_t row_offset, full_height;
+  vkr_gbuffer_scene scene;
+};
+
+constexpr int kSphereChunk = 128;
+
+struct Hit {
+  float t;        // ray parameter in units of (far point - camera); 1 = far plane
+  int32_t what;   // -1 none, -2 ground, >= 0 sphere index
+};
+
+__global__ __launch_bounds__(256) void gbuffer_fill_kernel(const FillParams p) {
+  __shared__ float4 s_sphere[kSphereChunk];  // centre.xyz, radius
+  const uint32_t t = threadIdx.x;
+  const uint32_t x0 = blockIdx.x * 32u + (t & 7u) * 4u;
+  const uint32_t y = blockIdx.y * 32u + (t >> 3);
+  const bool inside = (x0 < p.o.width) && (y < p.o.height);
+  const vkr_gbuffer_scene& sc = p.scene;
+  const float* M = sc.inv_view_proj;
+  const float cam[3] = {sc.camera_pos[0], sc.camera_pos[1], sc.camera_pos[2]};
+
+  float dir[4][3];
+  Hit hit[4];
+  const float v = ((float)(y + p.row_offset) + 0.5f) / (float)p.full_height;
+  const float cy = v * 2.0f - 1.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float u = ((float)(x0 + i) + 0.5f) / (float)p.o.width;
+    const float cx = u * 2.0f - 1.0f;
+    // far-plane point of the pixel: inverse(VP) * (cx, cy, 1, 1), then the perspective divide
+    const float wx = ((M[0] * cx + M[4] * cy) + M[8]) + M[12];
+    const float wy = ((M[1] * cx + M[5] * cy) + M[9]) + M[13];
+    const float wz = ((M[2] * cx + M[6] * cy) + M[10]) + M[14];
+    const float ww = ((M[3] * cx + M[7] * cy) + M[11]) + M[15];
+    dir[i][0] = wx / ww - cam[0];
+    dir[i][1] = wy / ww - cam[1];
+    dir[i][2] = wz / ww - cam[2];
+    hit[i].t = 1.0f;
+    hit[i].what = -1;
+  }
+
+  for (uint32_t base = 0; base < sc.sphere_count; base += kSphereChunk) {
+    const uint32_t n = min((uint32_t)kSphereChunk, sc.sphere_count - base);
+    __syncthreads();
+    if (t < n) s_sphere[t] = make_float4(p.spheres[base + t].center[0], p.spheres[base + t].center[1], p.spheres[base + t].center[2], p.spheres[base + t].radius);
+    __syncthreads();
+    for (uint32_t s = 0; s < n; ++s) {
+      const float4 sp = s_sphere[s];
+      const float oc[3] = {cam[0] - sp.x, cam[1] - sp.y, cam[2] - sp.z};
+      const float c = ((oc[0] * oc[0] + oc[1] * oc[1]) + oc[2] * oc[2]) - sp.w * sp.w;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float a = (dir[i][0] * dir[i][0] + dir[i][1] * dir[i][1]) + dir[i][2] * dir[i][2];
+        const float b = (oc[0] * dir[i][0] + oc[1] * dir[i][1]) + oc[2] * dir[i][2];
+        const float disc = b * b - a * c;
+        if (disc >= 0.0f) {
+          const float tt = (-b - sqrtf(disc)) / a;
+          if (tt > 0.0f && tt < hit[i].t) {
+            hit[i].t = tt;
+            hit[i].what = (int32_t)(base + s);
+          }
+        }
+      }
+    }
+  }
+  const float gn[3] = {sc.ground_plane[0], sc.ground_plane[1], sc.ground_plane[2]};
+  const float gn2 = (gn[0] * gn[0] + gn[1] * gn[1]) + gn[2] * gn[2];
+  if (gn2 > 0.0f) {
+    const float dist = ((gn[0] * cam[0] + gn[1] * cam[1]) + gn[2] * cam[2]) + sc.ground_plane[3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float denom = (gn[0] * dir[i][0] + gn[1] * dir[i][1]) + gn[2] * dir[i][2];
+      if (denom < 0.0f) {  // the plane faces the ray
+        const float tt = -dist / denom;
+        if (tt > 0.0f && tt < hit[i].t) {
+          hit[i].t = tt;
+          hit[i].what = -2;
+        }
+      }
+    }
+  }
+  if (!inside) return;
+
+  const float* VP = sc.view_proj;
+  uint32_t alb[4], mat[4];
+  uint2 nrm[4];
+  float dep[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (hit[i].what == -1) {  // the clear values of /root/reference/src/main.cpp:125-129
+      alb[i] = 0xFF000000u;
+      mat[i] = 0xFF000000u;
+      nrm[i] = pack_half4(0.0f, 0.0f, 0.0f, 1.0f);
+      dep[i] = 1.0f;
+      continue;
+    }
+    const float P[3] = {cam[0] + dir[i][0] * hit[i].t, cam[1] + dir[i][1] * hit[i].t, cam[2] + dir[i][2] * hit[i].t};
+    float N[3], col[3], rough, metal, occ;
+    if (hit[i].what >= 0) {
+      const vkr_sphere& s = p.spheres[hit[i].what];
+      N[0] = (P[0] - s.center[0]) / s.radius;
+      N[1] = (P[1] - s.center[1]) / s.radius;
+      N[2] = (P[2] - s.center[2]) / s.radius;
+      col[0] = s.albedo[0];
+      col[1] = s.albedo[1];
+      col[2] = s.albedo[2];
+      rough = s.roughness;
+      metal = s.metalness;
+      occ = s.occlusion;
+    } else {
+      const float inv = 1.0f / sqrtf(gn2);
+      N[0] = gn[0] * inv;
+      N[1] = gn[1] * inv;
+      N[2] = gn[2] * inv;
+      const float s = floorf(P[0] / sc.ground_tile) + floorf(P[2] / sc.ground_tile);
+      const bool odd = (s - 2.0f * floorf(s * 0.5f)) != 0.0f;
+      const float* g = odd ? sc.ground_albedo_b : sc.ground_albedo_a;
+      col[0] = g[0];
+      col[1] = g[1];
+      col[2] = g[2];
+      rough = sc.ground_roughness;
+      metal = sc.ground_metalness;
+      occ = 1.0f;
+    }
+    const float cz = ((VP[2] * P[0] + VP[6] * P[1]) + VP[10] * P[2]) + VP[14];
+    const float cw = ((VP[3] * P[0] + VP[7] * P[1]) + VP[11] * P[2]) + VP[15];
+    alb[i] = pack_unorm8x4(col[0], col[1], col[2], 1.0f);
+    mat[i] = pack_unorm8x4(occ, rough, metal, 1.0f);
+    nrm[i] = pack_half4(-N[0], -N[1], -N[2], 1.0f);
+    dep[i] = cz / cw;
+  }
+  const uint32_t valid = min(4u, p.o.width - x0);
+  uint32_t* pa = reinterpret_cast<uint32_t*>(p.o.albedo + (size_t)y * p.o.pitch_albedo) + x0;
+  uint32_t* pm = reinterpret_cast<uint32_t*>(p.o.material + (size_t)y * p.o.pitch_material) + x0;
+  uint2* pn = reinterpret_cast<uint2*>(p.o.normal + (size_t)y * p.o.pitch_normal) + x0;
+  float* pd = reinterpret_cast<float*>(p.o.depth + (size_t)y * p.o.pitch_depth) + x0;
+  if (valid == 4u) {
+    *reinterpret_cast<uint4*>(pa) = make_uint4(alb[0], alb[1], alb[2], alb[3]);
+    *reinterpret_cast<uint4*>(pm) = make_uint4(mat[0], mat[1], mat[2], mat[3]);
+    *reinterpret_cast<uint4*>(pn) = make_uint4(nrm[0].x, nrm[0].y, nrm[1].x, nrm[1].y);
+    *reinterpret_cast<uint4*>(pn + 2) = make_uint4(nrm[2].x, nrm[2].y, nrm[3].x, nrm[3].y);
+    *reinterpret_cast<float4*>(pd) = make_float4(dep[0], dep[1], dep[2], dep[3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if ((uint32_t)i < valid) {
+        pa[i] = alb[i];
+        pm[i] = mat[i];
+        pn[i] = nrm[i];
+        pd[i] = dep[i];
+      }
+    }
+  }
+}
+
+int32_t check_plane(const vkr_image2d& im, const char* what, uint32_t fmt_a, uint32_t fmt_b, uint32_t texel, uint32_t w, uint32_t h) {
+  if (!im.device) return vkr_fail(VKR_ERR_INVALID_ARGUMENT, "%s: null image", what);
+  if (im.format != fmt_a && im.format != fmt_b) return vkr_fail(VKR_ERR_INVALID_ARGUMENT, "%s: format %u not accepted", what, im.format);
+  if (im.width != w || im.height != h) return vkr_fail(VKR_ERR_INVALID_ARGUMENT, "%s: extent %ux%u differs from %ux%u", what, im.width, im.height, w, h);
+  if (im.pitch_bytes < w * texel || (im.pitch_bytes & 15u) || (reinterpret_cast<uintptr_t>(im.device) & 15u))
+    return vkr_fail(VKR_ERR_INVALID_ARGUMENT, "%s: pitch %u / base must be 16-byte aligned and cover a row", what, im.pitch_bytes);
+  return VKR_OK;
+}
+
+int32_t planes_from(const vkr_image2d& albedo, const vkr_image2d& material, const vkr_image2d& normal, const vkr_image2d& depth, Planes* o) {
+  const uint32_t w = albedo.width, h = albedo.height;
+  if (w == 0u || h == 0u || w > 32768u || h > 32768u) return vkr_fail(VKR_ERR_INVALID_ARGUMENT, "extent %ux%u out of range", w, h);
+  if (int32_t rc = check_plane(albedo, "albedo", VKR_FORMAT_R8G8B8A8_UNORM, VKR_FORMAT_R8G8B8A8_UNORM, 4, w, h)) return rc;
+  if (int32_t rc = check_plane(material, "material", VKR_FORMAT_R8G8B8A8_UNORM, VKR_FORMAT_R8G8B8A8_UNORM, 4, w, h)) return rc;
+  if (int32_t rc = check_plane(normal, "normal", VKR_FORMAT_R16G16B16A16_SFLOAT, VKR_FORMAT_R16G16B16A16_SFLOAT, 8, w, h)) return rc;
+  if (int32_t rc = check_plane(depth, "depth", VKR_FORMAT_D32_SFLOAT, VKR_FORMAT_R32_SFLOAT, 4, w, h)) return rc;
+  o->albedo = static_cast<uint8_t*>(albedo.device);
+  o->material = static_cast<uint8_t*>(material.device);
+  o->normal = static_cast<uint8_t*>(normal.device);
+  o->depth = static_cast<uint8_t*>(depth.device);
+  o->pitch_albedo = albedo.pitch_bytes;
+  o->pitch_material = material.pitch_bytes;
+  o->pitch_normal = normal.pitch_bytes;
+  o->pitch_depth = depth.pitch_bytes;
+  o->width = w;
+  o->height = h;
+  return VKR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t vkr_gbuffer_encode(vkr_context* ctx, const vkr_gbuffer_encode_args* a) {
+  if (!ctx || !a) return vkr_fail(VKR_ERR_INVALID_ARGUMENT, "vkr_gbuffer_encode: null argument");
+  Planes o;
+  if (int32_t rc = planes_from(a->albedo, a->material, a->normal, a->depth, &o)) return rc;
+  if (!a->albedo_f32 || !a->material_f32 || !a->normal_f32 || !a->depth_f32) return vkr_fail(VKR_ERR_INVALID_ARGUMENT, "vkr_gbuffer_encode: null source plane");
+  if ((reinterpret_cast<uintptr_t>(a->albedo_f32) | reinterpret_cast<uintptr_t>(a->material_f32) | reinterpret_cast<uintptr_t>(a->normal_f32)) & 15u)
+    return vkr_fail(VKR_ERR_INVALID_ARGUMENT, "vkr_gbuffer_encode: float4 source planes must be 16-byte aligned");
+  VKR_HIP(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(gbuffer_encode_kernel, dim3((o.width + 255u) / 256u, (o.height + 3u) / 4u), dim3(256), 0, ctx->stream,
+                     static_cast<const float4*>(a->albedo_f32), static_cast<const float4*>(a->material_f32), static_cast<const float4*>(a->normal_f32),
+                     static_cast<const float*>(a->depth_f32), o);
+  VKR_HIP(hipGetLastError());
+  return VKR_OK;
+}
+
+int32_t vkr_gbuffer_fill(vkr_context* ctx, const vkr_gbuffer_fill_args* a) {
+  if (!ctx || !a) return vkr_fail(VKR_ERR_INVALID_ARGUMENT, "vkr_gbuffer_fill: null argument");
+  FillParams p{};
+  if (int32_t rc = planes_from(a->albedo, a->material, a->normal, a->depth, &p.o)) return rc;
+  if (a->scene.sphere_count && !a->spheres) return vkr_fail(VKR_ERR_INVALID_ARGUMENT, "vkr_gbuffer_fill: %u spheres but a null table", a->scene.sphere_count);
+  if (!(a->scene.ground_tile > 0.0f)) return vkr_fail(VKR_ERR_INVALID_ARGUMENT, "vkr_gbuffer_fill: ground_tile must be > 0");
+  p.spheres = static_cast<const vkr_sphere*>(a->spheres);
+  p.row_offset = a->row_offset;
+  p.full_height = a->full_height ? a->full_height : p.o.height;
+  if ((uint64_t)p.row_offset + p.o.height > p.full_height)
+    return vkr_fail(VKR_ERR_INVALID_ARGUMENT, "vkr_gbuffer_fill: rows [%u, %u) exceed full_height %u", p.row_offset, p.row_offset + p.o.height, p.full_height);
+  p.scene = a->scene;
+  VKR_HIP(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(gbuffer_fill_kernel, dim3((p.o.width + 31u) / 32u, (p.o.height + 31u) / 32u), dim3(256), 0, ctx->stream, p);
+  VKR_HIP(hipGetLastError());
+  return VKR_OK;
+}
+
+}  // extern "C"

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "vkr_c.h"
+#include "vkr_internal.h"
 #include "vkr_kernels.h"
 #include "vkr_math.h"
 
@@ -23,23 +24,7 @@ namespace {
 
 thread_local std::string g_last_error;
 
-int32_t fail(int32_t code, const char* fmt, ...) {
-  char buf[512];
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(buf, sizeof(buf), fmt, ap);
-  va_end(ap);
-  g_last_error = buf;
-  return code;
-}
-
-#define VKR_HIP(expr)                                                                              \
-  do {                                                                                             \
-    hipError_t e_ = (expr);                                                                        \
-    if (e_ != hipSuccess)                                                                          \
-      return fail(e_ == hipErrorOutOfMemory ? VKR_ERR_OUT_OF_MEMORY : VKR_ERR_DEVICE, "%s: %s", #expr, \
-                  hipGetErrorString(e_));                                                          \
-  } while (0)
+#define fail vkr_fail
 
 uint32_t format_texel_bytes(uint32_t f) {
   switch (f) {
@@ -58,12 +43,6 @@ uint32_t format_texel_bytes(uint32_t f) {
 }
 
 }  // namespace
-
-struct vkr_context {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  hipDeviceProp_t props{};
-};
 
 struct vkr_buffer {
   vkr_context* ctx = nullptr;
@@ -338,6 +317,16 @@ int32_t replay(vkr_context* ctx, const Dispatch& d) {
 }
 
 }  // namespace
+
+int32_t vkr_fail(int32_t code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
 
 extern "C" {
 

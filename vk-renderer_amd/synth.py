@@ -230,3 +230,120 @@ def cull_case(instance_count: int, mesh_count: int = 1024, config_index: int = 0
     scene["camera"] = cam
     scene["planes"] = cam["planes"]
     return scene
+
+
+# ------------------------------------------------------------------------------------------ scene trees
+
+SEED_SCENE = 0x5EED2001
+MESH_VALID = 7  # has faces | has uv0 | has triangles
+
+
+def make_scene_tree(node_count: int, mesh_count: int, seed: int = SEED_SCENE, *, refs_per_node: float = 1.5, invalid_every: int = 7) -> dict:
+    """A random node tree standing in for an imported aiScene: node i > 0 hangs under a random earlier
+    node, local transforms are rotation * scale + translation written as aiMatrix4x4 rows (a1..d4), every
+    node references a few meshes; every `invalid_every`-th mesh lacks texture coordinates (skipped by
+    /root/reference/src/vkmodel.cpp:91-93).  Returns nodes / meshes lists plus per-mesh vertex positions."""
+    u = uniform(seed, 0, node_count * 16)
+    parent = np.zeros(node_count, np.int64)
+    for i in range(1, node_count):
+        parent[i] = int(u[i] * i)
+    children = [[] for _ in range(node_count)]
+    for i in range(1, node_count):
+        children[parent[i]].append(i)
+    ang = uniform(seed, 1, node_count * 3) * 2 * np.pi
+    scl = 0.5 + uniform(seed, 2, node_count) * 1.5
+    trn = (uniform(seed, 3, node_count * 3).reshape(-1, 3) - 0.5) * 40.0
+    nref = (uniform(seed, 4, node_count) * 2 * refs_per_node).astype(np.int64)
+    pick = u64_stream(seed, 5, int(nref.sum()) + 1)
+    nodes, k = [], 0
+    for i in range(node_count):
+        a, b, c = ang[3 * i:3 * i + 3]
+        rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+        ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+        rz = np.array([[np.cos(c), -np.sin(c), 0], [np.sin(c), np.cos(c), 0], [0, 0, 1]])
+        m = np.eye(4)
+        m[:3, :3] = (rz @ ry @ rx) * scl[i]
+        m[:3, 3] = trn[i]
+        refs = [int(pick[k + j] % np.uint64(mesh_count)) for j in range(int(nref[i]))] if mesh_count else []
+        k += int(nref[i])
+        nodes.append((m.astype(np.float32).reshape(16), children[i], refs))  # row-major = a1..d4
+    vcount = 3 + (u64_stream(seed, 6, mesh_count) % np.uint64(200)).astype(np.int64)
+    fcount = 1 + (u64_stream(seed, 7, mesh_count) % np.uint64(300)).astype(np.int64)
+    meshes = []
+    for m in range(mesh_count):
+        flags = MESH_VALID if (invalid_every == 0 or (m + 1) % invalid_every) else (MESH_VALID & ~2)
+        meshes.append((int(vcount[m]), int(fcount[m]), m % 11, flags))
+    ext = 0.05 * np.exp(uniform(seed, 8, mesh_count) * np.log(200.0))  # half-extents 0.05 .. 10
+    positions = []
+    for m in range(mesh_count):
+        p = (uniform(seed, 100 + m, int(vcount[m]) * 3).reshape(-1, 3) - 0.5) * 2.0 * ext[m]
+        positions.append(p.astype(np.float32))
+    return {"nodes": nodes, "meshes": meshes, "positions": positions}
+
+
+def kept_positions(tree: dict, source_mesh: np.ndarray) -> np.ndarray:
+    """The packed position stream of the vertex buffer: kept meshes in table order (vkmodel.cpp:99,116)."""
+    parts = [tree["positions"][int(m)] for m in source_mesh]
+    return np.concatenate(parts).astype(np.float32) if parts else np.zeros((0, 3), np.float32)
+
+
+def make_instance_soup(instance_count: int, mesh_count: int, seed: int = SEED_SCENE) -> dict:
+    """Large flat instance set for timing the bounds kernel: contiguous per-mesh runs of random rigid
+    transforms (no tree), mesh bounds log-uniform."""
+    cuts = np.sort((uniform(seed, 20, mesh_count - 1) * instance_count).astype(np.int64)) if mesh_count > 1 else np.zeros(0, np.int64)
+    mesh_base = np.concatenate([[0], cuts, [instance_count]]).astype(np.uint32)
+    q = uniform(seed, 21, instance_count * 4).reshape(-1, 4) - 0.5
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    w, x, y, z = q.T
+    rot = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y + z * w), 2 * (x * z - y * w),
+                    2 * (x * y - z * w), 1 - 2 * (x * x + z * z), 2 * (y * z + x * w),
+                    2 * (x * z + y * w), 2 * (y * z - x * w), 1 - 2 * (x * x + y * y)], axis=1)  # columns
+    s = (0.5 + uniform(seed, 22, instance_count) * 1.5)[:, None]
+    t = (uniform(seed, 23, instance_count * 3).reshape(-1, 3) - 0.5) * 2000.0
+    mats = np.zeros((instance_count, 16), np.float32)
+    mats[:, 0:3] = rot[:, 0:3] * s
+    mats[:, 4:7] = rot[:, 3:6] * s
+    mats[:, 8:11] = rot[:, 6:9] * s
+    mats[:, 12:15] = t
+    mats[:, 15] = 1.0
+    ext = 0.05 * np.exp(uniform(seed, 24, mesh_count) * np.log(1000.0))
+    ctr = (uniform(seed, 25, mesh_count * 3).reshape(-1, 3) - 0.5) * 4.0
+    mesh_aabb = np.zeros((mesh_count, 8), np.float32)
+    mesh_aabb[:, 0:3] = ctr - ext[:, None]
+    mesh_aabb[:, 4:7] = ctr + ext[:, None]
+    return {"mesh_base": mesh_base, "mesh_matrices": mats, "mesh_aabb": mesh_aabb}
+
+
+# ------------------------------------------------------------------------------------------ analytic scenes
+
+def make_spheres(count: int, seed: int = SEED_SCENE, *, region: float = 60.0, centre=(0.0, 3.0, 30.0)) -> np.ndarray:
+    """`count` spheres scattered in front of the reference camera (48-byte vkr_sphere records)."""
+    hm = _hostmath()
+    s = np.zeros(count, hm.SPHERE_DTYPE)
+    u = uniform(seed, 30, count * 12).reshape(-1, 12)
+    s["center"] = (np.asarray(centre) + (u[:, 0:3] - 0.5) * region).astype(np.float32)
+    s["radius"] = (0.5 + u[:, 3] * 4.0).astype(np.float32)
+    s["albedo"] = u[:, 4:7].astype(np.float32)
+    s["roughness"] = u[:, 7].astype(np.float32)
+    s["metalness"] = (u[:, 8] > 0.5).astype(np.float32)
+    s["occlusion"] = u[:, 9].astype(np.float32)
+    return s
+
+
+def fscene_text(count: int, seed: int = SEED_SCENE, *, spot_every: int = 4) -> str:
+    """A .fscene-shaped JSON document: `count` lights, every `spot_every`-th one not a point light, plus
+    unrelated keys of the kinds such files carry."""
+    import json
+    u = uniform(seed, 40, count * 12).reshape(-1, 12)
+    lights = []
+    for i in range(count):
+        kind = "dir_light" if spot_every and (i + 1) % spot_every == 0 else "point_light"
+        lights.append({"name": f"light{i}", "type": kind,
+                       "intensity": [float(np.float32(u[i, 0] * 80)), float(u[i, 1] * 80), float(u[i, 2] * 80)],
+                       "pos": [float((u[i, 3] - 0.5) * 100), float(u[i, 4] * 10), float((u[i, 5] - 0.5) * 100)],
+                       "direction": [float(u[i, 6] - 0.5), -1.0, float(u[i, 7] - 0.5)],
+                       "opening_angle": float(u[i, 8] * 360.0), "penumbra_angle": float(u[i, 9] * 30.0),
+                       "extra": {"nested": [1, 2, {"deep": 'va"lue \\ end'}], "flag": True, "none": None}})
+    doc = {"version": 2, "models": [{"file": "scene.fbx", "instances": [{"name": "main", "translation": [0, 0, 0]}]}],
+           "lights": lights, "cameras": [{"name": "cam", "pos": [0, 3, 71]}], "user_defined": {"tone": 1.5e-3}}
+    return json.dumps(doc, indent=1)
