@@ -57,6 +57,80 @@ def profiled_traffic():
     return out, os.path.relpath(files[-1], ROOT)
 
 
+def timed(ctx, fn, iters, warmup):
+    """Average milliseconds of fn() over `iters` back-to-back calls on the library's stream (HIP events)."""
+    for _ in range(warmup):
+        fn()
+    ctx.wait_idle()
+    e0 = ctx.marker()
+    for _ in range(iters):
+        fn()
+    e1 = ctx.marker()
+    ctx.wait_idle()
+    return e1.elapsed_ms_since(e0) / iters
+
+
+def bench_callers(ctx, vkr, synth, args, K, WU, rank, world, barrier):
+    """The steps before the two passes, each on the headline sizes: per-instance bounds (2^22 instances),
+    G-buffer attachment encode and analytic fill (4K), and the 64-frame camera path (cull + fill + resolve
+    per frame, three frames in flight).  Per-rank figures; every rank runs the same work."""
+    import ctypes as C
+    frame = importlib.import_module("vk-renderer_amd.frame")
+    W, H, L = args.width, args.height, args.lights
+    N, M = args.instances, args.meshes
+    out = {}
+
+    soup = synth.make_instance_soup(N, M)
+    mats, base, mesh = ctx.buffer_from(soup["mesh_matrices"]), ctx.buffer_from(soup["mesh_base"]), ctx.buffer_from(soup["mesh_aabb"])
+    mn, mx = ctx.buffer(N * 16), ctx.buffer(N * 16)
+    ms = timed(ctx, lambda: vkr._check(vkr.lib().vkr_instance_aabbs(ctx.handle, mats.ptr, base.ptr, mesh.ptr, M, N, mn.ptr, mx.ptr)), K, WU)
+    byt = N * 96.0  # 64-byte matrix in, two float4 out
+    out["instance_aabbs"] = {"value": N / (ms * 1e-3) / 1e9, "unit": "G instances/s", "ms_per_call": ms,
+                             "roofline": {"bound": "hbm", "achieved": byt / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                          "frac": byt / (ms * 1e-3) / HBM_PEAK, "traffic": None, "algorithmic_bytes": byt}}
+    del mats, mn, mx
+
+    gb = vkr.GBuffer(ctx, W, H)
+    rng = np.random.default_rng(1)
+    planes = [ctx.buffer_from(rng.random((H, W, 4), dtype=np.float32)) for _ in range(3)] + [ctx.buffer_from(rng.random((H, W), dtype=np.float32))]
+    ms = timed(ctx, lambda: frame.gbuffer_encode(ctx, gb, *planes), K, WU)
+    byt = W * H * 72.0  # 52 bytes of float planes in, 20 bytes of attachments out
+    out["gbuffer_encode"] = {"value": W * H / (ms * 1e-3) / 1e9, "unit": "Gpixel/s", "ms_per_call": ms,
+                             "roofline": {"bound": "hbm", "achieved": byt / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                          "frac": byt / (ms * 1e-3) / HBM_PEAK, "traffic": None, "algorithmic_bytes": byt}}
+    del planes
+
+    cam = synth.reference_camera(W, H)
+    spheres = synth.make_spheres(64)
+    sbuf = ctx.buffer_from(spheres)
+    sc = frame.make_gbuffer_scene(cam["vp"], cam["inv_vp"], cam["pos"], 64)
+    ms = timed(ctx, lambda: frame.gbuffer_fill(ctx, gb, sbuf, sc), K, WU)
+    byt = W * H * 20.0
+    # per (pixel, sphere): b = dot (5), disc = b*b - a*c (3), one compare; per pixel ~110 for the ray, the ground,
+    # the hit's attributes and the encodes (FMA would count as 2; this file is compiled without contraction)
+    flops = W * H * (110.0 + 9.0 * 64)
+    out["gbuffer_fill"] = {"value": W * H / (ms * 1e-3) / 1e9, "unit": "Gpixel/s", "ms_per_call": ms, "spheres": 64,
+                           "roofline": {"bound": "valu_fp32", "achieved": flops / (ms * 1e-3) / 1e12, "peak": VALU_FP32_PEAK / 1e12, "unit": "TFLOP/s",
+                                        "frac": flops / (ms * 1e-3) / VALU_FP32_PEAK, "traffic": None, "algorithmic_flops": flops,
+                                        "algorithmic_bytes": byt, "hbm_frac": byt / (ms * 1e-3) / HBM_PEAK}}
+
+    # camera path: 64 frames, each = cull of the N-instance set + analytic fill + resolve with L lights
+    scene = synth.cull_case(N, M, config_index=2 + 10 * rank)
+    cs = vkr.CullScene(ctx, scene["aabb_min"], scene["aabb_max"], scene["mesh_base"], scene["cmd_template"])
+    lights = synth.deferred_case(64, 36, L, config_index=5)["lights"]
+    loop = frame.FrameLoop(ctx, W, H, np.ascontiguousarray(lights, np.float32).reshape(-1, 12), spheres, cs, frames_in_flight=3)
+    camera = frame.Camera()
+    loop.run_path(camera, 3)  # warm-up
+    barrier()
+    t0 = time.perf_counter()
+    frames = 64
+    loop.run_path(camera, frames)
+    dt = time.perf_counter() - t0
+    out["camera_path"] = {"value": frames / dt, "unit": "frames/s", "ms_per_frame": dt / frames * 1e3, "frames": frames,
+                          "workload": f"per frame: cull {N} instances, analytic G-buffer fill {W}x{H}, resolve with {L} lights; 3 frames in flight"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,6 +143,7 @@ def main():
     ap.add_argument("--meshes", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cull", action="store_true")
+    ap.add_argument("--no-callers", action="store_true", help="skip the steps either side of the passes (bounds, G-buffer producers, camera path)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -239,6 +314,10 @@ def main():
         cull["config"] = {"workload": f"frustum cull + compaction, {N} instance AABBs, {M} meshes, {nsets} rotating input sets",
                           "parallelism": f"replicated scene x{world}"}
         result["cull"] = cull
+
+    # ---------------------------------------------------------------- callers either side of the passes
+    if not args.no_callers and not args.no_cull:
+        result["callers"] = bench_callers(ctx, vkr, synth, args, K, WU, rank, world, barrier)
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1)
     if world == 1 and not args.no_cpu_baseline:

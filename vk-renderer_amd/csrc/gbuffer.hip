@@ -46,42 +46,38 @@ struct Planes {
   uint32_t width, height;
 };
 
-// ---------------------------------------------------------------- encode: one lane = four pixels of a row
+// ---------------------------------------------------------------- encode
+// A 256-thread workgroup converts 1024 consecutive pixels of one row: lane t takes pixels t, t+256,
+// t+512, t+768 of that run, so every load is one fully used 16-byte lane slot (4 KiB per wave and
+// instruction) and every store a contiguous dword / qword per lane.
 __global__ __launch_bounds__(256) void gbuffer_encode_kernel(const float4* __restrict__ albedo, const float4* __restrict__ material,
                                                              const float4* __restrict__ normal, const float* __restrict__ depth, Planes o) {
-  const uint32_t x0 = (blockIdx.x * 64u + (threadIdx.x & 63u)) * 4u;
-  const uint32_t y = blockIdx.y * 4u + (threadIdx.x >> 6);
-  if (x0 >= o.width || y >= o.height) return;
-  const uint32_t n = min(4u, o.width - x0);
-  const size_t base = (size_t)y * o.width + x0;
-  uint32_t a[4], m[4];
-  uint2 nn[4];
-  float d[4];
+  const uint32_t y = blockIdx.y;
+  const uint32_t x_first = blockIdx.x * 1024u + threadIdx.x;
+  const size_t row = (size_t)y * o.width;
+  float4 av[4], mv[4], nv[4];
+  float dv[4];
 #pragma unroll
   for (uint32_t i = 0; i < 4u; ++i) {
-    const size_t p = base + (i < n ? i : 0u);
-    const float4 av = load_stream(albedo + p), mv = load_stream(material + p), nv = load_stream(normal + p);
-    a[i] = pack_unorm8x4(av.x, av.y, av.z, av.w);
-    m[i] = pack_unorm8x4(mv.x, mv.y, mv.z, mv.w);
-    nn[i] = pack_half4(nv.x, nv.y, nv.z, nv.w);
-    d[i] = __builtin_nontemporal_load(depth + p);
+    const uint32_t x = x_first + i * 256u;
+    const size_t p = row + (x < o.width ? x : 0u);
+    av[i] = load_stream(albedo + p);
+    mv[i] = load_stream(material + p);
+    nv[i] = load_stream(normal + p);
+    dv[i] = __builtin_nontemporal_load(depth + p);
   }
-  uint32_t* pa = reinterpret_cast<uint32_t*>(o.albedo + (size_t)y * o.pitch_albedo) + x0;
-  uint32_t* pm = reinterpret_cast<uint32_t*>(o.material + (size_t)y * o.pitch_material) + x0;
-  uint2* pn = reinterpret_cast<uint2*>(o.normal + (size_t)y * o.pitch_normal) + x0;
-  float* pd = reinterpret_cast<float*>(o.depth + (size_t)y * o.pitch_depth) + x0;
-  if (n == 4u) {
-    *reinterpret_cast<uint4*>(pa) = make_uint4(a[0], a[1], a[2], a[3]);
-    *reinterpret_cast<uint4*>(pm) = make_uint4(m[0], m[1], m[2], m[3]);
-    *reinterpret_cast<uint4*>(pn) = make_uint4(nn[0].x, nn[0].y, nn[1].x, nn[1].y);
-    *reinterpret_cast<uint4*>(pn + 2) = make_uint4(nn[2].x, nn[2].y, nn[3].x, nn[3].y);
-    *reinterpret_cast<float4*>(pd) = make_float4(d[0], d[1], d[2], d[3]);
-  } else {
-    for (uint32_t i = 0; i < n; ++i) {
-      pa[i] = a[i];
-      pm[i] = m[i];
-      pn[i] = nn[i];
-      pd[i] = d[i];
+  uint32_t* pa = reinterpret_cast<uint32_t*>(o.albedo + (size_t)y * o.pitch_albedo);
+  uint32_t* pm = reinterpret_cast<uint32_t*>(o.material + (size_t)y * o.pitch_material);
+  uint2* pn = reinterpret_cast<uint2*>(o.normal + (size_t)y * o.pitch_normal);
+  float* pd = reinterpret_cast<float*>(o.depth + (size_t)y * o.pitch_depth);
+#pragma unroll
+  for (uint32_t i = 0; i < 4u; ++i) {
+    const uint32_t x = x_first + i * 256u;
+    if (x < o.width) {
+      pa[x] = pack_unorm8x4(av[i].x, av[i].y, av[i].z, av[i].w);
+      pm[x] = pack_unorm8x4(mv[i].x, mv[i].y, mv[i].z, mv[i].w);
+      pn[x] = pack_half4(nv[i].x, nv[i].y, nv[i].z, nv[i].w);
+      pd[x] = dv[i];
     }
   }
 }
@@ -286,7 +282,7 @@ int32_t vkr_gbuffer_encode(vkr_context* ctx, const vkr_gbuffer_encode_args* a) {
   if ((reinterpret_cast<uintptr_t>(a->albedo_f32) | reinterpret_cast<uintptr_t>(a->material_f32) | reinterpret_cast<uintptr_t>(a->normal_f32)) & 15u)
     return vkr_fail(VKR_ERR_INVALID_ARGUMENT, "vkr_gbuffer_encode: float4 source planes must be 16-byte aligned");
   VKR_HIP(hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(gbuffer_encode_kernel, dim3((o.width + 255u) / 256u, (o.height + 3u) / 4u), dim3(256), 0, ctx->stream,
+  hipLaunchKernelGGL(gbuffer_encode_kernel, dim3((o.width + 1023u) / 1024u, o.height), dim3(256), 0, ctx->stream,
                      static_cast<const float4*>(a->albedo_f32), static_cast<const float4*>(a->material_f32), static_cast<const float4*>(a->normal_f32),
                      static_cast<const float*>(a->depth_f32), o);
   VKR_HIP(hipGetLastError());
