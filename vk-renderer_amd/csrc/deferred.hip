@@ -66,15 +66,17 @@ __device__ __forceinline__ float pow5_(float t) {
 }
 __device__ __forceinline__ float const_inv151() { return __uint_as_float(0x3F298953u); }  // 1.0/1.51 as folded
 
-// Four transcendentals, each followed by one idle cycle (s_nop 0).  Measured on gfx950
-// (tools/gen_ubench_trans3.py): in a stream of plain VALU work a transcendental whose wave tries to
-// issue its next VALU instruction in the very next cycle costs 14 plain issue slots at 4 waves per
-// SIMD; with one idle cycle after it, 7.  The idle cycle also covers the wait state a transcendental
-// result needs before a plain VALU instruction may read it, which the compiler cannot see inside an
-// asm statement.
+// Four transcendentals, each followed by one idle cycle (s_nop 0), issued under raised wave priority.
+// Measured on gfx950 at 4 waves per SIMD (tools/gen_ubench_trans3.py, gen_ubench_trans4.py), in a stream
+// of plain VALU work: a transcendental whose wave tries to issue its next VALU instruction in the very
+// next cycle costs 14 plain issue slots; with one idle cycle after it, 6.4; and 4.8 when the four issue
+// back to back without another wave's instructions in between, which the priority bracket arranges.
+// The idle cycle also covers the wait state a transcendental result needs before a plain VALU
+// instruction may read it, which the compiler cannot see inside an asm statement.
 #define VKR_TRANS4(NAME, OP)                                                                            \
   __device__ __forceinline__ void NAME(float (&o)[4], const float (&x)[4]) {                            \
-    asm(OP " %0, %4\n\ts_nop 0\n\t" OP " %1, %5\n\ts_nop 0\n\t" OP " %2, %6\n\ts_nop 0\n\t" OP " %3, %7\n\ts_nop 0" \
+    asm("s_setprio 3\n\t" OP " %0, %4\n\ts_nop 0\n\t" OP " %1, %5\n\ts_nop 0\n\t" OP " %2, %6\n\ts_nop 0\n\t" OP \
+        " %3, %7\n\ts_nop 0\n\ts_setprio 0"                                                          \
         : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])                                            \
         : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));                                                  \
   }
