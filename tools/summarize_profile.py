@@ -39,7 +39,8 @@ for f in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     for k, cs in agg.items():
-        m = re.search(r"(\w+)(<[^>]*>)?\([^()]*\)$", k)  # function name (+ template arguments) before the parameter list
+        flat = k.replace("(anonymous namespace)::", "")
+        m = re.search(r"(\w+)(<[^>(]*>)?\(", flat)  # function name (+ template arguments) before the parameter list
         short = (m.group(1) + (m.group(2) or "")) if m else k
         for c, v in cs.items():
             # skip the first dispatches (clock ramp / cold caches)

@@ -19,7 +19,8 @@ COMMON = ["--offload-arch=gfx950", "-fPIC", "-std=c++17", "-fvisibility=hidden",
 UNITS = [
     # -fno-slp-vectorize: v_pk_*_f32 issues at half the rate of the scalar forms on gfx950, so packing
     # two pixels into one instruction gains nothing and costs ~6 % here.
-    # -falign-loops=32: the light loop's header on a 32-byte fetch boundary (measured: up to 10 % between placements).
+    # -falign-loops=32: loop headers on 32-byte boundaries (harmless; the placement sensitivity once seen
+    # here was the transcendental issue hazard that the kernel now avoids explicitly).
     ("deferred.hip", ["-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-falign-loops=32"]),
     ("cull.hip", ["-O3", "-ffp-contract=off"]),
     ("scene.hip", ["-O3", "-ffp-contract=off"]),

@@ -475,9 +475,7 @@ __global__ __launch_bounds__(256, 4) void deferred_kernel(const DeferredParams p
   uint32_t list_count = 0;
   float last[2][3] = {};  // float outputs: the second pair's colours
 
-  // One copy of the light loop serves both pixel pairs (no unrolling): the loop's issue time moves by
-  // 10 % with the placement of its instructions relative to 32-byte fetch windows, and one copy whose
-  // header is put on a 32-byte boundary (-falign-loops=32 in the build) is the placement that measured best.
+  // One copy of the light loop serves both pixel pairs (no unrolling): half the code, same speed.
 #pragma unroll 1
   for (int g = 0; g < 4; g += 2) {
     Pixel s[2];
