@@ -70,7 +70,7 @@ def timed(ctx, fn, iters, warmup):
     return e1.elapsed_ms_since(e0) / iters
 
 
-def bench_callers(ctx, vkr, synth, args, K, WU, rank, world, barrier):
+def bench_callers(ctx, vkr, synth, args, K, WU, rank, world, barrier, pmc):
     """The steps before the two passes, each on the headline sizes: per-instance bounds (2^22 instances),
     G-buffer attachment encode and analytic fill (4K), and the 64-frame camera path (cull + fill + resolve
     per frame, three frames in flight).  Per-rank figures; every rank runs the same work."""
@@ -87,7 +87,7 @@ def bench_callers(ctx, vkr, synth, args, K, WU, rank, world, barrier):
     byt = N * 96.0  # 64-byte matrix in, two float4 out
     out["instance_aabbs"] = {"value": N / (ms * 1e-3) / 1e9, "unit": "G instances/s", "ms_per_call": ms,
                              "roofline": {"bound": "hbm", "achieved": byt / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                                          "frac": byt / (ms * 1e-3) / HBM_PEAK, "traffic": None, "algorithmic_bytes": byt}}
+                                          "frac": byt / (ms * 1e-3) / HBM_PEAK, "traffic": pmc.get("instance_aabb_kernel"), "algorithmic_bytes": byt}}
     del mats, mn, mx
 
     gb = vkr.GBuffer(ctx, W, H)
@@ -97,7 +97,7 @@ def bench_callers(ctx, vkr, synth, args, K, WU, rank, world, barrier):
     byt = W * H * 72.0  # 52 bytes of float planes in, 20 bytes of attachments out
     out["gbuffer_encode"] = {"value": W * H / (ms * 1e-3) / 1e9, "unit": "Gpixel/s", "ms_per_call": ms,
                              "roofline": {"bound": "hbm", "achieved": byt / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                                          "frac": byt / (ms * 1e-3) / HBM_PEAK, "traffic": None, "algorithmic_bytes": byt}}
+                                          "frac": byt / (ms * 1e-3) / HBM_PEAK, "traffic": pmc.get("gbuffer_encode_kernel"), "algorithmic_bytes": byt}}
     del planes
 
     cam = synth.reference_camera(W, H)
@@ -111,7 +111,7 @@ def bench_callers(ctx, vkr, synth, args, K, WU, rank, world, barrier):
     flops = W * H * (110.0 + 9.0 * 64)
     out["gbuffer_fill"] = {"value": W * H / (ms * 1e-3) / 1e9, "unit": "Gpixel/s", "ms_per_call": ms, "spheres": 64,
                            "roofline": {"bound": "valu_fp32", "achieved": flops / (ms * 1e-3) / 1e12, "peak": VALU_FP32_PEAK / 1e12, "unit": "TFLOP/s",
-                                        "frac": flops / (ms * 1e-3) / VALU_FP32_PEAK, "traffic": None, "algorithmic_flops": flops,
+                                        "frac": flops / (ms * 1e-3) / VALU_FP32_PEAK, "traffic": pmc.get("gbuffer_fill_kernel"), "algorithmic_flops": flops,
                                         "algorithmic_bytes": byt, "hbm_frac": byt / (ms * 1e-3) / HBM_PEAK}}
 
     # camera path: 64 frames, each = cull of the N-instance set + analytic fill + resolve with L lights
@@ -317,7 +317,7 @@ def main():
 
     # ---------------------------------------------------------------- callers either side of the passes
     if not args.no_callers and not args.no_cull:
-        result["callers"] = bench_callers(ctx, vkr, synth, args, K, WU, rank, world, barrier)
+        result["callers"] = bench_callers(ctx, vkr, synth, args, K, WU, rank, world, barrier, pmc if default_workload else {})
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1)
     if world == 1 and not args.no_cpu_baseline:
