@@ -58,10 +58,51 @@ def main():
     np.savez_compressed(os.path.join(HERE, "cull_adversarial_65536.npz"), **arrays)
     manifest["cull_adversarial_65536.npz"] = {k: sha(v) for k, v in arrays.items()}
 
+    # ---- callers either side of the passes (scene_oracle.c) ------------------------------------------
+    frame = importlib.import_module("vk-renderer_amd.frame")
+    vkr = importlib.import_module("vk-renderer_amd")
+    tree = synth.make_scene_tree(40, 9, synth.SEED_SCENE)
+    t = oracle.scene_tables(tree["nodes"], [(v, f, m, 1 if fl == 7 else 0) for v, f, m, fl in tree["meshes"]])
+    positions = synth.kept_positions(tree, t["source_mesh"])
+    mesh = oracle.mesh_aabbs(positions, t["vertex_base"])
+    mn, mx = oracle.instance_aabbs(t["mesh_matrices"], t["mesh_base"], mesh)
+    arrays = dict(node_transform=np.stack([n[0] for n in tree["nodes"]]), node_children=np.array([len(n[1]) for n in tree["nodes"]], np.uint32),
+                  positions=positions, mesh_info=t["mesh_info"], draw_commands=t["draw_commands"], per_mesh_data=t["per_mesh_data"],
+                  mesh_matrices=t["mesh_matrices"], mesh_base=t["mesh_base"], vertex_base=t["vertex_base"], source_mesh=t["source_mesh"],
+                  mesh_aabb=mesh, aabb_min=mn, aabb_max=mx)
+    np.savez_compressed(os.path.join(HERE, "scene_40nodes_9meshes.npz"), **arrays)
+    manifest["scene_40nodes_9meshes.npz"] = {k: sha(v) for k, v in arrays.items()}
+
+    w, h = 96, 54
+    cam = synth.reference_camera(w, h)
+    spheres = synth.make_spheres(12, synth.SEED_SCENE + 1)
+    sc = frame.make_gbuffer_scene(cam["vp"], cam["inv_vp"], cam["pos"], 12)
+    g = oracle.gbuffer_fill(bytes(sc), spheres, w, h)
+    arrays = dict(scene=np.frombuffer(bytes(sc), np.uint8), spheres=spheres.view(np.uint8), albedo=g["albedo"], material=g["material"],
+                  normal=g["normal"], depth=g["depth"])
+    np.savez_compressed(os.path.join(HERE, "gbuffer_fill_96x54_12spheres.npz"), **arrays)
+    manifest["gbuffer_fill_96x54_12spheres.npz"] = {k: sha(v) for k, v in arrays.items()}
+
+    text = synth.fscene_text(9, synth.SEED_SCENE + 2)
+    with open(os.path.join(HERE, "lights_9.fscene"), "w") as f:
+        f.write(text)
+    recs = oracle.fscene_point_lights(text)
+    ocam = oracle.Camera.default()
+    states = []
+    for _ in range(16):
+        ocam.key(0, 2.5)
+        ocam.cursor_delta(np.float32(1.0 / 60.0), 0.0)
+        states.append(np.concatenate([ocam.state()[:6], ocam.view()]))
+    arrays = dict(light_records=recs, camera_path=np.stack(states).astype(np.float32))
+    np.savez_compressed(os.path.join(HERE, "lights_camera.npz"), **arrays)
+    manifest["lights_camera.npz"] = {k: sha(v) for k, v in arrays.items()}
+    manifest["lights_9.fscene"] = {"text": hashlib.sha256(text.encode()).hexdigest()}
+
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     for k in manifest:
         print(k, os.path.getsize(os.path.join(HERE, k)))
+    del vkr
 
 
 if __name__ == "__main__":

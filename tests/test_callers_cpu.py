@@ -268,3 +268,45 @@ def test_new_struct_layouts(vkr):
     assert C.sizeof(vkr.SceneCounts) == 20 and C.sizeof(vkr.SceneTables) == 56 and C.sizeof(vkr.SceneDesc) == 88
     assert vkr.SPHERE_DTYPE.itemsize == 48 and vkr.LIGHT_INFO_DTYPE.itemsize == 48
     assert vkr.LIGHT_INFO_DTYPE.fields["color"][1] == 16 and vkr.LIGHT_INFO_DTYPE.fields["dir"][1] == 32
+
+
+# ------------------------------------------------------------------------------------------ committed fixtures
+
+GOLDEN = __import__("os").path.join(__import__("os").path.dirname(__file__), "golden")
+
+
+def test_golden_scene_and_lights(vkr, synth, oracle, scene_mod, frame_mod):
+    """The oracle and the product's host code both reproduce the committed fixtures byte for byte."""
+    z = np.load(GOLDEN + "/scene_40nodes_9meshes.npz")
+    tree = synth.make_scene_tree(40, 9, synth.SEED_SCENE)
+    assert np.array_equal(np.stack([n[0] for n in tree["nodes"]]), z["node_transform"])  # the generator is stable
+    o = oracle.scene_tables(tree["nodes"], [(v, f, m, 1 if fl == 7 else 0) for v, f, m, fl in tree["meshes"]])
+    tb = scene_mod.build_tables(scene_mod.SceneDescription(tree["nodes"], tree["meshes"]))
+    for k in ("mesh_matrices", "mesh_base", "vertex_base", "source_mesh"):
+        assert np.array_equal(o[k], z[k]) and np.array_equal(tb[k], z[k]), k
+    assert o["draw_commands"].tobytes() == z["draw_commands"].tobytes() == tb["draw_commands"].tobytes()
+    assert np.array_equal(tb["mesh_info"].view(np.uint32).reshape(-1, 4), z["mesh_info"])
+    positions = synth.kept_positions(tree, tb["source_mesh"])
+    assert np.array_equal(positions, z["positions"])
+    mesh = oracle.mesh_aabbs(positions, tb["vertex_base"])
+    mn, mx = oracle.instance_aabbs(tb["mesh_matrices"], tb["mesh_base"], mesh)
+    assert np.array_equal(mesh.view(np.uint32), z["mesh_aabb"].view(np.uint32))
+    assert np.array_equal(mn.view(np.uint32), z["aabb_min"].view(np.uint32)) and np.array_equal(mx.view(np.uint32), z["aabb_max"].view(np.uint32))
+
+    text = open(GOLDEN + "/lights_9.fscene").read()
+    zl = np.load(GOLDEN + "/lights_camera.npz")
+    assert oracle.fscene_point_lights(text).tobytes() == zl["light_records"].tobytes()
+    assert frame_mod.fscene_point_lights(text).tobytes() == zl["light_records"].tobytes()
+    cam = frame_mod.Camera()
+    for want in zl["camera_path"]:
+        cam.step_path(0.5, 1.0)
+        assert np.array_equal(np.concatenate([cam.pos, cam.forward, cam.view()]), want)
+
+
+def test_golden_gbuffer_fill(oracle):
+    z = np.load(GOLDEN + "/gbuffer_fill_96x54_12spheres.npz")
+    g = oracle.gbuffer_fill(z["scene"].tobytes(), z["spheres"], 96, 54)
+    for k in ("albedo", "material", "depth"):
+        assert np.array_equal(g[k], z[k]), k
+    assert np.array_equal(g["normal"].view(np.uint16), z["normal"].view(np.uint16))
+    assert 0.3 < (z["depth"] < 1.0).mean() < 1.0

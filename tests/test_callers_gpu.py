@@ -279,3 +279,29 @@ def test_frame_loop_camera_path(vkr, ctx, synth, oracle, frame_mod):
     ref_c = oracle.cull(scene["aabb_min"], scene["aabb_max"], frame_mod.frame_setup(cams[7], proj)["planes"], scene["mesh_base"], scene["cmd_template"])
     assert cs.results()["cmds"].tobytes() == ref_c["cmds"].tobytes()
     assert not np.array_equal(loop.outputs[0].download(np.uint8, 4), loop.outputs[1].download(np.uint8, 4))  # the camera moved
+
+
+# ------------------------------------------------------------------------------------------ committed fixtures
+
+def test_golden_fixtures(vkr, ctx, scene_mod, frame_mod):
+    import os
+    golden = os.path.join(os.path.dirname(__file__), "golden")
+    z = np.load(os.path.join(golden, "scene_40nodes_9meshes.npz"))
+    tables = {"counts": {"kept_meshes": len(z["source_mesh"]), "kept_instances": len(z["mesh_matrices"])},
+              "vertex_base": z["vertex_base"], "mesh_base": z["mesh_base"], "mesh_matrices": z["mesh_matrices"]}
+    ds = scene_mod.DeviceScene(ctx, tables, z["positions"])
+    ds.compute_mesh_aabbs()
+    ds.compute_instance_aabbs()
+    got = ds.download()
+    assert np.array_equal(bits(got["mesh_aabb"]), bits(z["mesh_aabb"]))
+    assert np.array_equal(bits(got["aabb_min"]), bits(z["aabb_min"])) and np.array_equal(bits(got["aabb_max"]), bits(z["aabb_max"]))
+
+    z = np.load(os.path.join(golden, "gbuffer_fill_96x54_12spheres.npz"))
+    sc = vkr.GBufferScene.from_buffer_copy(z["scene"].tobytes())
+    gb = vkr.GBuffer(ctx, 96, 54)
+    sbuf = ctx.buffer_from(z["spheres"])
+    frame_mod.gbuffer_fill(ctx, gb, sbuf, sc)
+    ctx.wait_idle()
+    assert np.array_equal(gb.albedo.download(np.uint8, 4), z["albedo"]) and np.array_equal(gb.material.download(np.uint8, 4), z["material"])
+    assert np.array_equal(gb.normal.download(np.uint16, 4), z["normal"].view(np.uint16))
+    assert np.array_equal(bits(gb.depth.download(np.float32, 1)), bits(z["depth"]))
