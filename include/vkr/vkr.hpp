@@ -26,6 +26,8 @@
 #include <cstring>
 #include <functional>
 #include <initializer_list>
+#include <fstream>
+#include <iterator>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -592,6 +594,124 @@ class StagingBuffer : public Buffer {
   std::vector<Copy> mCopies;
   uint64_t mUsedBytes = 0;
   Queue& mQueue;
+};
+
+// ---------------------------------------------------------------- callers of the two passes
+using Mat4 = std::array<float, 16>;  // column-major, like glm::mat4
+
+// glm::perspective as /root/reference/src/main.cpp:95 calls it.
+inline Mat4 perspective(float fovyRadians, float aspect, float zNear, float zFar) {
+  Mat4 m;
+  vkr_perspective(fovyRadians, aspect, zNear, zFar, m.data());
+  return m;
+}
+
+// Key and action codes with GLFW's values, so that a window callback can forward them unchanged.
+namespace Key {
+constexpr int eSpace = 32, eA = 65, eD = 68, eS = 83, eW = 87, eLeftShift = 340;
+constexpr int eRelease = 0, ePress = 1, eRepeat = 2;
+}  // namespace Key
+
+// CameraInputHandler of /root/reference/inc/vkcamera.hpp:9-67 (same member functions; GLFW types dropped).
+class CameraInputHandler {
+ public:
+  CameraInputHandler() { vkr_camera_default(&mCamera); }
+  void onCursorPosChange(double x, double y) {
+    const float nx = static_cast<float>(x), ny = static_cast<float>(y);
+    if (mHasPrevCursorPos) vkr_camera_cursor_delta(&mCamera, nx - mPrevCursorPos[0], ny - mPrevCursorPos[1]);
+    mPrevCursorPos = {nx, ny};
+    mHasPrevCursorPos = true;
+  }
+  void onKeyEvent(int key, int action, [[maybe_unused]] int mods = 0) {
+    if (action == Key::eRelease) return;
+    int32_t k = -1;
+    switch (key) {
+      case Key::eW: k = VKR_KEY_W; break;
+      case Key::eA: k = VKR_KEY_A; break;
+      case Key::eS: k = VKR_KEY_S; break;
+      case Key::eD: k = VKR_KEY_D; break;
+      case Key::eSpace: k = VKR_KEY_SPACE; break;
+      case Key::eLeftShift: k = VKR_KEY_LEFT_SHIFT; break;
+      default: return;
+    }
+    vkr_camera_key(&mCamera, k, static_cast<float>(mDeltaTime));
+  }
+  void setLastDeltaTime(int64_t microseconds) { mDeltaTime = static_cast<double>(microseconds) / 10000.0; }
+  Mat4 getView() const {
+    Mat4 m;
+    vkr_camera_view(&mCamera, m.data());
+    return m;
+  }
+  std::array<float, 3> getPos() const { return {mCamera.pos[0], mCamera.pos[1], mCamera.pos[2]}; }
+  std::array<float, 3> getForward() const { return {mCamera.forward[0], mCamera.forward[1], mCamera.forward[2]}; }
+  const vkr_camera& state() const { return mCamera; }
+
+ private:
+  vkr_camera mCamera;
+  double mDeltaTime = 1.0;
+  std::array<float, 2> mPrevCursorPos{};
+  bool mHasPrevCursorPos = false;
+};
+
+// view, vp = proj * view, inverse(vp), DeferredPushData and the cull planes for one frame
+// (/root/reference/src/main.cpp:206-209).
+inline vkr_frame_constants frameConstants(const CameraInputHandler& camera, const Mat4& proj) {
+  vkr_frame_constants fc;
+  check(vkr_frame_setup(&camera.state(), proj.data(), &fc), "vkr::frameConstants");
+  return fc;
+}
+
+// The point lights of a .fscene file as LightInfo records (/root/reference/src/main.cpp:40-70).
+inline std::vector<vkr_light_info> loadPointLights(const std::string& path) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) throw std::runtime_error("File " + path + " does not exist!");
+  const std::string text((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  uint32_t n = 0;
+  check(vkr_fscene_point_lights(text.data(), text.size(), nullptr, 0, &n), "vkr::loadPointLights");
+  std::vector<vkr_light_info> lights(n);
+  if (n) check(vkr_fscene_point_lights(text.data(), text.size(), lights.data(), n, &n), "vkr::loadPointLights");
+  return lights;
+}
+
+inline vkr_image2d imageDesc(const Image& im) {
+  return {im.storage().devicePtr(), im.extent().width, im.extent().height, im.pitch(), static_cast<uint32_t>(im.format())};
+}
+
+// Stands in for the raster G-buffer pass of /root/reference/src/main.cpp:214-219 in tests and benches: an
+// analytic scene written into the four attachments (stream-ordered with the queue's submissions).
+inline void fillGBuffer(Device& device, const Image& albedo, const Image& material, const Image& normal, const Image& depth, const Buffer& spheres,
+                        const vkr_gbuffer_scene& scene) {
+  vkr_gbuffer_fill_args a{};
+  a.albedo = imageDesc(albedo);
+  a.material = imageDesc(material);
+  a.normal = imageDesc(normal);
+  a.depth = imageDesc(depth);
+  a.spheres = spheres.devicePtr();
+  a.scene = scene;
+  check(vkr_gbuffer_fill(device.getHandle(), &a), "vkr::fillGBuffer");
+}
+
+// The tables vw::Scene::Scene builds (/root/reference/src/vkmodel.cpp:55-111) from a flattened scene description.
+struct SceneTables {
+  vkr_scene_counts counts{};
+  std::vector<vkr_mesh_info> meshInfo;
+  std::vector<vkr_draw_indexed_indirect_command> drawCommands;
+  std::vector<vkr_per_mesh_data> perMeshData;
+  std::vector<float> meshMatrices;
+  std::vector<uint32_t> meshBase, vertexBase, sourceMesh;
+
+  explicit SceneTables(const vkr_scene_desc& desc) {
+    check(vkr_scene_count(&desc, &counts), "vkr::SceneTables");
+    meshInfo.resize(counts.kept_meshes);
+    drawCommands.resize(counts.kept_meshes);
+    perMeshData.resize(counts.kept_meshes);
+    meshMatrices.resize(size_t(counts.kept_instances) * 16);
+    meshBase.resize(counts.kept_meshes + 1);
+    vertexBase.resize(counts.kept_meshes + 1);
+    sourceMesh.resize(counts.kept_meshes);
+    vkr_scene_tables t{meshInfo.data(), drawCommands.data(), perMeshData.data(), meshMatrices.data(), meshBase.data(), vertexBase.data(), sourceMesh.data()};
+    check(vkr_scene_build_tables(&desc, &counts, &t), "vkr::SceneTables");
+  }
 };
 
 }  // namespace vkr

@@ -162,3 +162,52 @@ def test_band_push_extension_and_host_visible_buffer(vkr, synth, ctx):
     vkr.Fence(f).wait()
     assert np.array_equal(band.download(np.uint8, 4), want[7:18])
     lib.vkr_cmd_destroy(cmd)
+
+
+def test_cpp_camera_path(vkr, synth, oracle, tmp_path):
+    """tests/cpp/camera_path.cpp: .fscene lights, CameraInputHandler driven by key / cursor events, per-frame
+    constants, three command buffers in flight.  Checked against the oracle chain for the last three frames."""
+    import importlib
+    frame = importlib.import_module("vk-renderer_amd.frame")
+    exe = os.path.join(ROOT, "tests", "cpp", "camera_path")
+    assert os.path.exists(exe), "tests/cpp/camera_path is built by __graft_entry__.build()"
+    w, h, frames = 160, 90, 7
+    d = str(tmp_path)
+    np.array([w, h, frames], np.uint32).tofile(os.path.join(d, "meta.bin"))
+    text = synth.fscene_text(14, 77)
+    doc = __import__("json").loads(text)
+    for i, l in enumerate(doc["lights"]):  # put the lights where the spheres are
+        l["pos"] = [float((i % 5 - 2) * 9.0), 8.0 + i % 3, 20.0 + 4.0 * (i // 5)]
+        l["intensity"] = [120.0 + 10 * i, 90.0, 200.0 - 8 * i]
+    text = __import__("json").dumps(doc)
+    open(os.path.join(d, "scene.fscene"), "w").write(text)
+    spheres = synth.make_spheres(15, 8)
+    spheres.tofile(os.path.join(d, "spheres.bin"))
+    r = subprocess.run([exe, d], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lights = oracle.fscene_point_lights(text)
+    assert f"frames={frames}" in r.stdout and f"lights={lights.shape[0]}" in r.stdout
+    # camera states logged by the program = the oracle camera under the same events
+    log = np.fromfile(os.path.join(d, "camera_log.bin"), np.float32).reshape(frames, 6)
+    ocam = oracle.Camera.default()
+    proj = frame.reference_projection(w, h)
+    x = np.float32(100.0)
+    xd = 100.0
+    for f in range(frames):
+        assert np.array_equal(log[f], ocam.state()[:6]), f
+        if f >= frames - 3:
+            view = ocam.view()
+            vp = vkr.mat4_mul(proj, view)
+            inv = vkr.mat4_inverse(vp)
+            sc = frame.make_gbuffer_scene(vp, inv, ocam.state()[:3], 15)
+            g = oracle.gbuffer_fill(bytes(sc), spheres, w, h)
+            push = vkr.deferred_push(ocam.state()[:3], inv, 1.0)
+            ref = oracle.deferred(g, lights, push, mode="mix", want=("rgba8",))
+            got = np.fromfile(os.path.join(d, f"out{f % 3}.bin"), np.uint8).reshape(h, w, 4)
+            assert np.abs(got.astype(int) - ref["rgba8"].astype(int)).max() <= 1, f
+            assert got[..., :3].max() > 30
+        ocam.key(0, np.float32(2.5))
+        xd += 1.0 / 60.0
+        nx = np.float32(xd)
+        ocam.cursor_delta(float(nx - x), 0.0)
+        x = nx
