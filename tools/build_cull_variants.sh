@@ -5,7 +5,7 @@ mkdir -p vk-renderer_amd/lib/variants
 COMMON="--offload-arch=gfx950 -fPIC -std=c++17 -fvisibility=hidden -I include -I vk-renderer_amd/csrc"
 while [ $# -gt 0 ]; do
   name=$1; flags=$2; shift 2
-  /opt/rocm/bin/hipcc -c vk-renderer_amd/csrc/cull.hip -o /tmp/cull_$name.o $COMMON -O3 -ffp-contract=off $flags
-  /opt/rocm/bin/hipcc -shared -o vk-renderer_amd/lib/variants/libvkr_$name.so --offload-arch=gfx950 vk-renderer_amd/lib/deferred.o /tmp/cull_$name.o vk-renderer_amd/lib/vkr_api.o
+  /opt/rocm/bin/hipcc -c ${CULL_SRC:-vk-renderer_amd/csrc/cull.hip} -o /tmp/cull_$name.o $COMMON -O3 -ffp-contract=off $flags
+  /opt/rocm/bin/hipcc -shared -o vk-renderer_amd/lib/variants/libvkr_$name.so --offload-arch=gfx950 vk-renderer_amd/lib/deferred.o /tmp/cull_$name.o vk-renderer_amd/lib/vkr_api.o vk-renderer_amd/lib/scene.o vk-renderer_amd/lib/gbuffer.o vk-renderer_amd/lib/vkr_host.o
   echo built $name
 done

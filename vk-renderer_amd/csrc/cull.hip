@@ -23,6 +23,10 @@
 
 #include "vkr_kernels.h"
 
+#ifndef VKR_ATOMIC_PER_LANE
+#define VKR_ATOMIC_PER_LANE 4
+#endif
+
 namespace {
 
 constexpr uint32_t kBlockThreads = 256;
@@ -69,18 +73,27 @@ __global__ __launch_bounds__(256) void cull_init_cmds(const CullParams p) {
   p.cmd_out[m] = c;
 }
 
-// Loads and tests the four instances of this lane.  Instance of (wave chunk, row k, lane l) is
+constexpr uint32_t kAtomicPerLane = VKR_ATOMIC_PER_LANE;
+constexpr uint32_t kAtomicChunk = 64u * kAtomicPerLane;  // instances per wave and loop trip
+__device__ __forceinline__ bool any_pending(const uint64_t (&pend)[kAtomicPerLane]) {
+  uint64_t all = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kAtomicPerLane; ++k) all |= pend[k];
+  return all != 0ull;
+}
+
+// Loads and tests the instances of this lane.  Instance of (wave chunk, row k, lane l) is
 // chunk*256 + k*64 + l, so every wave-level load covers 1 KiB of contiguous memory.
 struct LaneWork {
-  bool vis[kPerLane];
-  uint32_t mesh[kPerLane];  // local mesh index (global id - first_mesh)
+  bool vis[kAtomicPerLane];
+  uint32_t mesh[kAtomicPerLane];  // local mesh index (global id - first_mesh)
 };
 
 __device__ __forceinline__ LaneWork test_four(const CullParams& p, uint32_t chunk_base, uint32_t lane, bool& bad) {
-  float4 mn[kPerLane], mx[kPerLane];
-  bool in[kPerLane];
+  float4 mn[kAtomicPerLane], mx[kAtomicPerLane];
+  bool in[kAtomicPerLane];
 #pragma unroll
-  for (uint32_t k = 0; k < kPerLane; ++k) {
+  for (uint32_t k = 0; k < kAtomicPerLane; ++k) {
     const uint32_t i = chunk_base + k * 64u + lane;
     in[k] = i < p.instance_count;
     const uint32_t ic = in[k] ? i : 0u;
@@ -89,7 +102,7 @@ __device__ __forceinline__ LaneWork test_four(const CullParams& p, uint32_t chun
   }
   LaneWork w;
 #pragma unroll
-  for (uint32_t k = 0; k < kPerLane; ++k) {
+  for (uint32_t k = 0; k < kAtomicPerLane; ++k) {
     w.mesh[k] = __float_as_uint(mn[k].w) - p.first_mesh;
     bool v = in[k] && aabb_visible(mn[k], mx[k], p.planes);
     if (v && w.mesh[k] >= p.mesh_count) {
@@ -102,29 +115,33 @@ __device__ __forceinline__ LaneWork test_four(const CullParams& p, uint32_t chun
 }
 
 // Counts accumulate in cmd_out[m].instanceCount, zeroed by cull_init_cmds in the launch before.
-// (Folding both into one launch needs a "last block" ticket; 2048 blocks incrementing one word
-// serialise at ~50 ns each and made the cull 4x slower than the extra 4 us launch costs.)
+// Folding both into one launch was tried twice and is no faster than the 4.5 us the extra launch costs:
+// (a) the first blocks initialise the records and bump a counter that every wave polls before its
+// first atomic - the waves reach the poll before the initialising blocks have pushed their stores out
+// (__threadfence) and stall for about as long as the launch took; with an agent-scope *acquire* in
+// the poll it is 3x slower, because that invalidates the XCD's L2 once per wave (the L2s of the
+// eight XCDs are not coherent with each other);  (b) a "last block" ticket at the end was 4x slower.
 __global__ __launch_bounds__(256) void cull_atomic_kernel(const CullParams p, uint32_t chunk_count) {
   const uint32_t lane = lane_id();
   const uint32_t wave = (blockIdx.x * kBlockThreads + threadIdx.x) >> 6;
   const uint32_t wave_stride = (gridDim.x * kBlockThreads) >> 6;
   bool bad = false;
   for (uint32_t chunk = wave; chunk < chunk_count; chunk += wave_stride) {
-    const uint32_t chunk_base = chunk * 256u;
+    const uint32_t chunk_base = chunk * kAtomicChunk;
     LaneWork w = test_four(p, chunk_base, lane, bad);
-    uint64_t pend[kPerLane];
+    uint64_t pend[kAtomicPerLane];
 #pragma unroll
-    for (uint32_t k = 0; k < kPerLane; ++k) pend[k] = __ballot(w.vis[k]);
+    for (uint32_t k = 0; k < kAtomicPerLane; ++k) pend[k] = __ballot(w.vis[k]);
     // one iteration per distinct mesh among this wave's visible instances (usually one)
-    while ((pend[0] | pend[1] | pend[2] | pend[3]) != 0ull) {
+    while (any_pending(pend)) {
       uint32_t m = 0;
 #pragma unroll
-      for (int k = kPerLane - 1; k >= 0; --k)
+      for (int k = kAtomicPerLane - 1; k >= 0; --k)
         if (pend[k] != 0ull) m = __builtin_amdgcn_readlane(w.mesh[k], (int)__builtin_ctzll(pend[k]));
-      uint64_t same[kPerLane];
+      uint64_t same[kAtomicPerLane];
       uint32_t total = 0;
 #pragma unroll
-      for (uint32_t k = 0; k < kPerLane; ++k) {
+      for (uint32_t k = 0; k < kAtomicPerLane; ++k) {
         same[k] = __ballot(w.vis[k] && w.mesh[k] == m);
         total += (uint32_t)__popcll(same[k]);
         pend[k] &= ~same[k];
@@ -133,7 +150,7 @@ __global__ __launch_bounds__(256) void cull_atomic_kernel(const CullParams p, ui
       if (lane == 0u) base = atomicAdd(&p.cmd_out[m].instanceCount, total);
       base = __builtin_amdgcn_readfirstlane(base) + p.mesh_base[m];
 #pragma unroll
-      for (uint32_t k = 0; k < kPerLane; ++k) {
+      for (uint32_t k = 0; k < kAtomicPerLane; ++k) {
         if (w.vis[k] && w.mesh[k] == m) {
           const uint32_t slot = base + rank_in(same[k]);
           if (slot < p.instance_count)
@@ -338,7 +355,7 @@ uint64_t vkr_cull_workspace_size(uint64_t n, uint32_t m) {
 
 hipError_t vkr_launch_cull_atomic(const CullParams& p, hipStream_t stream) {
   if (p.mesh_count == 0u) return hipSuccess;
-  const uint32_t chunks = (p.instance_count + 255u) / 256u;
+  const uint32_t chunks = (p.instance_count + kAtomicChunk - 1u) / kAtomicChunk;
   // 4 waves per block; cap the grid at 8 blocks per CU and let waves stride over chunks
   uint32_t blocks = (chunks + 3u) / 4u;
   if (blocks > 2048u) blocks = 2048u;
