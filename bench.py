@@ -159,18 +159,35 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # RCCL is the backend.  VKR_BENCH_BACKEND=gloo is a rehearsal of the N>1 control flow on a box with fewer
+    # GPUs than ranks: ranks share devices and the collectives go through host memory, so its numbers mean nothing.
+    backend = os.environ.get("VKR_BENCH_BACKEND", "nccl")
+    if backend not in ("nccl", "gloo"):
+        raise SystemExit(f"VKR_BENCH_BACKEND={backend}: expected nccl or gloo")
+    device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
+    coll_device = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group("gloo")
 
     def barrier():
         if world > 1:
             dist.barrier()
 
+    def max_over_ranks(seconds):
+        if world == 1:
+            return seconds
+        tt = torch.tensor([seconds], dtype=torch.float64, device=coll_device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
     vkr = importlib.import_module("vk-renderer_amd")
     synth = importlib.import_module("vk-renderer_amd.synth")
     vdist = importlib.import_module("vk-renderer_amd.dist")
-    ctx = vkr.Context(local_rank)
+    ctx = vkr.Context(device_index)
     info = ctx.device_info()
 
     W, H, L = args.width, args.height, args.lights
@@ -199,10 +216,7 @@ def main():
     t1 = time.perf_counter()
     wall = t1 - t0
     kern_ms = ev1.elapsed_ms_since(ev0) / K
-    if world > 1:
-        tt = torch.tensor([wall], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall = float(tt.item())
+    wall = max_over_ranks(wall)
     pixels_total = float(W) * H * K * world
     value = pixels_total / wall / 1e9
     dbytes, dflops = deferred_algorithmic(W, H, L)
@@ -243,7 +257,7 @@ def main():
         rows_max = vdist.band_rows(H, world, 0)[1]
         pitch = out.pitch
         band_t = torch.zeros(rows_max * pitch, dtype=torch.uint8, device="cuda")
-        full_t = torch.zeros(world * rows_max * pitch, dtype=torch.uint8, device="cuda")
+        full_t = torch.zeros(world * rows_max * pitch, dtype=torch.uint8, device=coll_device)
         band_img = vkr.Image2D(band_t.data_ptr(), W, r1 - r0, pitch, vkr.FORMAT_R8G8B8A8_UNORM)
         bargs = vkr.make_deferred_args(gb, out, lights, L, frame["push"], row0=r0, rows=r1 - r0)
         bargs.out = band_img
@@ -251,7 +265,7 @@ def main():
         def band_step():
             ctx.deferred_resolve(bargs)
             ctx.wait_idle()
-            dist.all_gather_into_tensor(full_t, band_t)
+            dist.all_gather_into_tensor(full_t, band_t if backend == "nccl" else band_t.cpu())
 
         for _ in range(WU):
             band_step()
@@ -262,10 +276,7 @@ def main():
             band_step()
         torch.cuda.synchronize()
         barrier()
-        tb = time.perf_counter() - tb0
-        tt = torch.tensor([tb], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        tb = float(tt.item())
+        tb = max_over_ranks(time.perf_counter() - tb0)
         result["band_sharded"] = {"value": float(W) * H * K / tb / 1e9, "unit": "Gpixel/s", "ms_per_frame": tb / K * 1e3,
                                   "scaling": "strong", "collective": "all_gather_into_tensor of rgba8 bands (RCCL)"}
 
@@ -296,11 +307,7 @@ def main():
             ctx.wait_idle()
             torch.cuda.synchronize()
             barrier()
-            cw = time.perf_counter() - c0
-            if world > 1:
-                tt = torch.tensor([cw], dtype=torch.float64, device="cuda")
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                cw = float(tt.item())
+            cw = max_over_ranks(time.perf_counter() - c0)
             call_ms = e1.elapsed_ms_since(e0) / K
             vis = int(css[0].results()["cmds"]["instanceCount"].sum())
             cb = cull_algorithmic(N, vis, M)
