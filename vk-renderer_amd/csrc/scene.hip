@@ -91,8 +91,10 @@ __device__ __forceinline__ uint32_t mesh_of(const uint32_t* __restrict__ mesh_ba
 constexpr int kInstBlock = 256;
 
 // One lane per instance.  The 64-byte matrices of a wave are one contiguous 4 KiB run: they are
-// fetched with fully coalesced 16-byte loads (lane l takes float4 number l, l+64, ... of the run) into
-// LDS and each lane then reads its own four columns back.
+// fetched with fully coalesced 16-byte loads (lane l takes float4 number l, l+256, ... of the block's run)
+// into LDS and each lane then reads its own four columns back.  The mesh lookup runs while those loads
+// are in flight: one binary search per workgroup for its first instance (uniform, so it runs on scalar
+// loads), then each lane steps forward over the few mesh boundaries inside the workgroup's 256 instances.
 __global__ __launch_bounds__(kInstBlock) void instance_aabb_kernel(const float4* __restrict__ matrices, const uint32_t* __restrict__ mesh_base,
                                                                    const float4* __restrict__ mesh_aabb, uint32_t mesh_count, uint32_t instance_count,
                                                                    float4* __restrict__ aabb_min, float4* __restrict__ aabb_max) {
@@ -100,15 +102,25 @@ __global__ __launch_bounds__(kInstBlock) void instance_aabb_kernel(const float4*
   const uint32_t block_first = blockIdx.x * kInstBlock;
   const uint32_t in_block = min((uint32_t)kInstBlock, instance_count - block_first);
   const float4* src = matrices + 4ull * block_first;
-  for (uint32_t k = threadIdx.x; k < 4u * in_block; k += kInstBlock) {
-    const uint32_t inst = k >> 2;
-    s_mat[k + (inst >> 4)] = load_stream(src + k);
+  const uint32_t t = threadIdx.x;
+  float4 staged[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t k = t + (uint32_t)j * kInstBlock;
+    if (k < 4u * in_block) staged[j] = load_stream(src + k);
+  }
+  const uint32_t i = block_first + t;
+  uint32_t m = mesh_of(mesh_base, mesh_count, block_first);
+  if (t < in_block) {
+    while (m + 1u < mesh_count && mesh_base[m + 1u] <= i) ++m;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t k = t + (uint32_t)j * kInstBlock;
+    if (k < 4u * in_block) s_mat[k + (k >> 6)] = staged[j];
   }
   __syncthreads();
-  const uint32_t t = threadIdx.x;
   if (t >= in_block) return;
-  const uint32_t i = block_first + t;
-  const uint32_t m = mesh_of(mesh_base, mesh_count, i);
   const float4 lo = mesh_aabb[2u * m], hi = mesh_aabb[2u * m + 1u];
   const float4* cols = s_mat + 4u * t + (t >> 4);
   const float4 c0 = cols[0], c1 = cols[1], c2 = cols[2], c3 = cols[3];
