@@ -149,7 +149,7 @@ typedef struct vkr_draw_indexed_indirect_command {
   uint32_t firstInstance;
 } vkr_draw_indexed_indirect_command;
 
-#define VKR_CULL_DETERMINISTIC 1u /* visible[] ascending inside each mesh segment (count -> scan -> scatter);
+#define VKR_CULL_DETERMINISTIC 1u /* visible[] ascending inside each mesh segment (mask -> place);
                                      default is one atomic per wave and mesh run (segment order unspecified) */
 
 /* The pass /root/reference/shaders/prep_indirect.comp:1-5 leaves empty.  Instance i carries a

@@ -91,6 +91,57 @@ def test_full_4m(vkr, synth, oracle, ctx, deterministic):
         _compare(cs.results(), ref, scene, False)
 
 
+def _with_segments(scene, vkr, sizes):
+    """The same boxes under a hand-made segment table: mesh k owns sizes[k] consecutive instances."""
+    sizes = np.asarray(sizes, np.int64)
+    n = scene["aabb_min"].shape[0]
+    assert int(sizes.sum()) == n
+    base = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint32)
+    mesh_of = np.repeat(np.arange(sizes.shape[0], dtype=np.uint32), sizes)
+    mn = scene["aabb_min"].copy()
+    mn[:, 3] = mesh_of.view(np.float32)
+    tmpl = np.zeros(sizes.shape[0], vkr.DRAW_CMD_DTYPE)
+    tmpl["indexCount"] = 3 * (1 + np.arange(sizes.shape[0]))
+    tmpl["firstIndex"] = 7 * np.arange(sizes.shape[0])
+    tmpl["vertexOffset"] = 11 * np.arange(sizes.shape[0])
+    return {"aabb_min": mn, "aabb_max": scene["aabb_max"], "mesh_base": base, "cmd_template": tmpl}
+
+
+@pytest.mark.parametrize("sizes", [
+    [0, 0, 5000, 0, 0],                                  # empty meshes first and last
+    [1024, 0, 1024, 0, 0, 2048, 904],                    # boundaries exactly on workgroup edges, empties on them
+    [1, 1023, 1, 0, 1024, 2047, 1, 903],                 # boundaries one off the edges
+    [0] * 300 + [5000] + [0] * 300,                      # more empty meshes than threads in a workgroup
+    [1] * 2500 + [2500],                                 # more meshes than instances per workgroup
+    [5000],
+])
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_segment_table_edges(vkr, synth, oracle, ctx, sizes, deterministic):
+    scene = _with_segments(synth.cull_case(5000, 4, config_index=3), vkr, sizes)
+    planes = synth.cull_case(16, 1)["planes"]
+    ref = oracle.cull(scene["aabb_min"], scene["aabb_max"], planes, scene["mesh_base"], scene["cmd_template"])
+    assert 0 < int(ref["mask"].sum()) < 5000
+    res, _ = _run(vkr, ctx, scene, planes, vkr.CULL_DETERMINISTIC if deterministic else 0)
+    _compare(res, ref, scene, deterministic)
+    # and with every instance visible
+    everything = np.zeros((6, 4), np.float32)
+    everything[:, 3] = 1.0
+    ref = oracle.cull(scene["aabb_min"], scene["aabb_max"], everything, scene["mesh_base"], scene["cmd_template"])
+    assert int(ref["mask"].sum()) == 5000
+    res, _ = _run(vkr, ctx, scene, everything, vkr.CULL_DETERMINISTIC if deterministic else 0)
+    _compare(res, ref, scene, deterministic)
+
+
+@pytest.mark.parametrize("n", [8192 * 1024, 8192 * 1024 + 1, 9_000_037])
+def test_deterministic_beyond_the_single_launch_placement(vkr, synth, oracle, ctx, n):
+    """Up to 8192 workgroups (2^23 instances) the placement launch sums the block counts itself; above that a
+    scan launch goes in between.  Both sides of the switch, complete comparison."""
+    scene = synth.cull_case(n, 777, config_index=4)
+    ref = oracle.cull(scene["aabb_min"], scene["aabb_max"], scene["planes"], scene["mesh_base"], scene["cmd_template"])
+    res, _ = _run(vkr, ctx, scene, scene["planes"], vkr.CULL_DETERMINISTIC)
+    _compare(res, ref, scene, True)
+
+
 def test_instance_range_sharding(vkr, synth, oracle, ctx):
     """Two calls over disjoint mesh ranges (cut at a mesh boundary) assemble into the single-call
     result: mesh ids stay global (first_mesh), indices are global (first_instance)."""

@@ -14,9 +14,10 @@
 //                        instanceCount field of the output command itself; lanes place their index
 //                        by mbcnt rank.  Order inside a mesh segment depends on wave arrival.
 //   deterministic mode : launch 1 writes one 64-bit visibility word per wave-row plus per-block
-//                        counts; launch 2 (one block) scans the block counts, ranks the mesh
-//                        boundaries and writes the commands; launch 3 scatters indices in
-//                        ascending order.
+//                        counts; launch 2 places the indices in ascending order and writes the
+//                        commands, each workgroup summing the counts of the workgroups before it
+//                        (up to 8192 of them; beyond that a single-workgroup scan launch goes in
+//                        between and the placement reads the scanned prefixes).
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -121,6 +122,8 @@ __device__ __forceinline__ LaneWork test_four(const CullParams& p, uint32_t chun
 // (__threadfence) and stall for about as long as the launch took; with an agent-scope *acquire* in
 // the poll it is 3x slower, because that invalidates the XCD's L2 once per wave (the L2s of the
 // eight XCDs are not coherent with each other);  (b) a "last block" ticket at the end was 4x slower.
+// Requesting the next chunk's boxes before working on the current one (so that the returning atomic waits
+// alongside those loads) was measured too: 31-32 us per call against 30, at any grid size.
 __global__ __launch_bounds__(256) void cull_atomic_kernel(const CullParams p, uint32_t chunk_count) {
   const uint32_t lane = lane_id();
   const uint32_t wave = (blockIdx.x * kBlockThreads + threadIdx.x) >> 6;
@@ -171,6 +174,7 @@ struct DetWorkspace {
   uint32_t* block_count;  // nblk
   uint32_t* block_prefix; // nblk + 1
   uint32_t* block_mesh;   // nblk + 1: local mesh index of each block's first instance; [nblk] = M-1
+  uint32_t* block_lo;     // nblk: mesh_base[block_mesh[b]] clamped to the block's first instance
   uint32_t* mesh_rank;    // M + 1
   uint16_t* word_prefix;  // nblk * 16: visible instances of the block before each 64-instance word
 };
@@ -189,10 +193,22 @@ __host__ __device__ inline DetWorkspace carve(void* base, uint64_t n, uint32_t m
   b += align_up((nblk + 1) * 4, 256);
   w.block_mesh = reinterpret_cast<uint32_t*>(b);
   b += align_up((nblk + 1) * 4, 256);
+  w.block_lo = reinterpret_cast<uint32_t*>(b);
+  b += align_up(nblk * 4, 256);
   w.mesh_rank = reinterpret_cast<uint32_t*>(b);
   b += align_up(((uint64_t)m + 1) * 4, 256);
   w.word_prefix = reinterpret_cast<uint16_t*>(b);
   return w;
+}
+
+// Largest m with mesh_base[m] <= i (0 if there is none).
+__device__ __forceinline__ uint32_t mesh_holding(const CullParams& p, uint32_t i) {
+  uint32_t lo = 0, hi = p.mesh_count - 1u;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi + 1u) >> 1;
+    if (p.mesh_base[mid] <= i) lo = mid; else hi = mid - 1u;
+  }
+  return lo;
 }
 
 // Pass A: one block per 1024 instances.
@@ -214,51 +230,87 @@ __global__ __launch_bounds__(256) void cull_mask_kernel(const CullParams p) {
     mn[k] = load_stream(p.aabb_min + ic);
     mx[k] = load_stream(p.aabb_max + ic);
   }
+  // The mesh id of every instance must agree with the segment table (deterministic mode relies on
+  // contiguity).  Usually a row of 64 instances lies in one mesh: its range comes from two scalar loads,
+  // and the loads of all four rows are requested together, ahead of the plane tests.
+  uint32_t mesh[kPerLane], row_lo[kPerLane], row_hi[kPerLane];
+  bool row_known[kPerLane];
+#pragma unroll
+  for (uint32_t k = 0; k < kPerLane; ++k) {
+    mesh[k] = __float_as_uint(mn[k].w) - p.first_mesh;
+    const uint32_t mesh0 = __builtin_amdgcn_readfirstlane(mesh[k]);  // lane 0 is in range whenever any lane of the row is
+    row_known[k] = mesh0 < p.mesh_count;
+    const uint32_t mc = row_known[k] ? mesh0 : 0u;
+    const uint32_t next = (mc + 1u < p.mesh_count) ? mc + 1u : mc;
+    row_lo[k] = p.mesh_base[mc];
+    const uint32_t after = p.mesh_base[next];
+    row_hi[k] = (mc + 1u < p.mesh_count) ? after : p.instance_count;
+  }
 #pragma unroll
   for (uint32_t k = 0; k < kPerLane; ++k) {
     const uint32_t i = blk * kBlockInstances + k * 256u + threadIdx.x;
-    const uint32_t mesh = __float_as_uint(mn[k].w) - p.first_mesh;
     bool v = in[k] && aabb_visible(mn[k], mx[k], p.planes);
-    if (in[k]) {
-      // the mesh id must agree with the segment table (deterministic mode relies on contiguity)
-      bool ok = mesh < p.mesh_count;
+    const uint64_t in_row = __ballot(in[k]);
+    const uint32_t mesh0 = __builtin_amdgcn_readfirstlane(mesh[k]);
+    bool ok = true;
+    if (__ballot(in[k] && mesh[k] != mesh0) == 0ull) {
+      const uint32_t row_first = i - lane, row_last = row_first + (uint32_t)__popcll(in_row) - 1u;
+      ok = (in_row == 0ull) || (row_known[k] && row_first >= row_lo[k] && row_last < row_hi[k]);
+    } else if (in[k]) {
+      ok = mesh[k] < p.mesh_count;
       if (ok) {
-        const uint32_t lo = p.mesh_base[mesh];
-        const uint32_t hi = (mesh + 1u < p.mesh_count) ? p.mesh_base[mesh + 1u] : p.instance_count;
+        const uint32_t lo = p.mesh_base[mesh[k]];
+        const uint32_t hi = (mesh[k] + 1u < p.mesh_count) ? p.mesh_base[mesh[k] + 1u] : p.instance_count;
         ok = (i >= lo) && (i < hi);
       }
-      if (!ok) {
-        bad = true;
-        v = false;
-      }
+    }
+    if (in[k] && !ok) {
+      bad = true;
+      v = false;
     }
     const uint64_t word = __ballot(v);
     if (lane == 0u) {
       ws.mask[(uint64_t)blk * kWordsPerBlock + k * 4u + wv] = word;
       word_count[k * 4u + wv] = (uint32_t)__popcll(word);
     }
-    if (k == 0u && threadIdx.x == 0u) ws.block_mesh[blk] = in[0] ? min(mesh, p.mesh_count - 1u) : p.mesh_count - 1u;
+    // mesh of the block's first instance; taken from the segment table when the instance's own id is wrong,
+    // so that the placement pass visits every mesh even for inconsistent input
+    if (k == 0u && threadIdx.x == 0u) {
+      const uint32_t m_first = ok ? mesh[k] : mesh_holding(p, i);
+      ws.block_mesh[blk] = m_first;
+      ws.block_lo[blk] = min(p.mesh_base[m_first], i);
+    }
   }
   __syncthreads();
   if (threadIdx.x < kWordsPerBlock) {
-    // exclusive prefix over the 16 word counts (one lane each, 16 LDS reads at most)
-    uint32_t before = 0;
-    for (uint32_t k = 0; k < threadIdx.x; ++k) before += word_count[k];
-    ws.word_prefix[(uint64_t)blk * kWordsPerBlock + threadIdx.x] = (uint16_t)before;
-    if (threadIdx.x == kWordsPerBlock - 1u) ws.block_count[blk] = before + word_count[kWordsPerBlock - 1u];
+    // exclusive prefix over the 16 word counts, in the first 16 lanes of wave 0
+    const uint32_t mine = word_count[threadIdx.x];
+    uint32_t s = mine;
+#pragma unroll
+    for (uint32_t d = 1; d < kWordsPerBlock; d <<= 1) {
+      const uint32_t o = __shfl_up(s, d);
+      if (threadIdx.x >= d) s += o;
+    }
+    ws.word_prefix[(uint64_t)blk * kWordsPerBlock + threadIdx.x] = (uint16_t)(s - mine);
+    if (threadIdx.x == kWordsPerBlock - 1u) ws.block_count[blk] = s;
   }
   if (threadIdx.x == 0u && blk == gridDim.x - 1u) ws.block_mesh[gridDim.x] = p.mesh_count - 1u;
   if (bad && p.error_flag) *p.error_flag = 1u;
 }
 
-// Global rank (number of visible instances with index < i): three independent loads.
-__device__ __forceinline__ uint32_t rank_before(const DetWorkspace& ws, uint32_t i) {
+// Number of visible instances of i's block with index < i: two independent loads.
+__device__ __forceinline__ uint32_t rank_in_block(const DetWorkspace& ws, uint32_t i) {
   const uint32_t blk = i / kBlockInstances;
   const uint32_t w = (i % kBlockInstances) >> 6;  // instance order inside a block is row-major over (k, wave, lane)
   const uint32_t bit = i & 63u;
   const uint64_t word = ws.mask[(uint64_t)blk * kWordsPerBlock + w];
   const uint32_t below = bit ? (uint32_t)__popcll(word & ((1ull << bit) - 1ull)) : 0u;
-  return ws.block_prefix[blk] + ws.word_prefix[(uint64_t)blk * kWordsPerBlock + w] + below;
+  return ws.word_prefix[(uint64_t)blk * kWordsPerBlock + w] + below;
+}
+
+// Global rank (number of visible instances with index < i), from the scanned block prefixes.
+__device__ __forceinline__ uint32_t rank_before(const DetWorkspace& ws, uint32_t i) {
+  return ws.block_prefix[i / kBlockInstances] + rank_in_block(ws, i);
 }
 
 // Pass C (same launch as B): rank of every mesh boundary, then the commands.
@@ -345,11 +397,124 @@ __global__ __launch_bounds__(256) void cull_scatter_kernel(const CullParams p) {
   }
 }
 
+// Passes B-D in one launch, for up to kPlaceMaxBlocks workgroups.  Workgroup b needs two prefix sums of
+// the block counts: up to itself, and up to the block in which the mesh of its first instance begins (the
+// only mesh of this workgroup whose first slot lies in an earlier block).  Both come out of one coalesced
+// pass over block_count[0, b), which stays in L2: 16 KiB at 2^22 instances.
+// The command of mesh m is written by the workgroup whose instance range (B0, B1] holds the mesh's end;
+// that workgroup knows the rank at both ends of the mesh.
+// The pass is bound by the latency of dependent loads, not by bytes: everything whose address depends only
+// on the workgroup index is requested first, which leaves the usual workgroup (one mesh throughout) with a
+// single dependent level, the rank at which that mesh begins.
+constexpr uint32_t kPlaceMaxBlocks = 8192;
+constexpr uint32_t kPlaceSumTrips = kPlaceMaxBlocks / (kBlockThreads * 4u);
+
+__global__ __launch_bounds__(256) void cull_place_kernel(const CullParams p, uint32_t nblk) {
+  __shared__ uint32_t s_part[2][kBlockThreads / 64];
+  const DetWorkspace ws = carve(p.workspace, p.instance_count, p.mesh_count);
+  const uint32_t blk = blockIdx.x;
+  const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+  const uint32_t n = p.instance_count;
+  const uint32_t b0 = blk * kBlockInstances, b1 = min(b0 + kBlockInstances, n);
+
+  // level 1: addresses known from the workgroup index alone
+  const uint32_t m_first = ws.block_mesh[blk];
+  const uint32_t m_last = ws.block_mesh[blk + 1u];
+  const uint32_t lo_first = ws.block_lo[blk];  // <= b0
+  const uint32_t count_here = ws.block_count[blk];
+  uint64_t word[kPerLane];
+  uint32_t word_before[kPerLane];
+#pragma unroll
+  for (uint32_t k = 0; k < kPerLane; ++k) {
+    word[k] = ws.mask[(uint64_t)blk * kWordsPerBlock + k * 4u + wv];
+    word_before[k] = ws.word_prefix[(uint64_t)blk * kWordsPerBlock + k * 4u + wv];
+  }
+  uint4 counts[kPlaceSumTrips];
+#pragma unroll
+  for (uint32_t it = 0; it < kPlaceSumTrips; ++it) {
+    const uint32_t j = it * kBlockThreads * 4u + threadIdx.x * 4u;
+    counts[it] = make_uint4(0u, 0u, 0u, 0u);
+    if (j < blk) counts[it] = *reinterpret_cast<const uint4*>(ws.block_count + j);  // the array is padded to 256 bytes
+  }
+  // level 2: rank inside its block of the instance at which mesh m_first begins
+  const uint32_t blk_first = lo_first / kBlockInstances;
+  const uint32_t rank_first_in_block = rank_in_block(ws, lo_first);
+
+  uint32_t sum_first = 0, sum_here = 0;
+#pragma unroll
+  for (uint32_t it = 0; it < kPlaceSumTrips; ++it) {
+    const uint32_t j = it * kBlockThreads * 4u + threadIdx.x * 4u;
+    const uint32_t v[4] = {counts[it].x, counts[it].y, counts[it].z, counts[it].w};
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) {
+      if (j + k < blk) sum_here += v[k];
+      if (j + k < blk_first) sum_first += v[k];
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    sum_first += __shfl_xor(sum_first, off);
+    sum_here += __shfl_xor(sum_here, off);
+  }
+  if (lane == 0u) {
+    s_part[0][wv] = sum_first;
+    s_part[1][wv] = sum_here;
+  }
+  __syncthreads();
+  sum_first = (s_part[0][0] + s_part[0][1]) + (s_part[0][2] + s_part[0][3]);
+  sum_here = (s_part[1][0] + s_part[1][1]) + (s_part[1][2] + s_part[1][3]);
+  const uint32_t rank_first = sum_first + rank_first_in_block;  // rank at which mesh m_first begins
+
+  // rank of boundary i, b0 <= i <= b1
+  auto rank_at = [&](uint32_t i) -> uint32_t { return sum_here + ((i >= b0 + kBlockInstances) ? count_here : rank_in_block(ws, i)); };
+
+  // commands of the meshes that end inside (b0, b1]; none when one mesh covers the block and goes on
+  const bool ends_here = (m_first != m_last) || (blk == 0u) || (b1 == n);
+  if (ends_here) {
+    for (uint32_t m = (blk == 0u ? 0u : m_first) + threadIdx.x; m <= m_last; m += kBlockThreads) {
+      const uint32_t lo = p.mesh_base[m];
+      const uint32_t hi = (m + 1u < p.mesh_count) ? p.mesh_base[m + 1u] : n;
+      const uint32_t lo_c = min(lo, n), hi_c = min(hi, n);
+      if (!((hi_c > b0 && hi_c <= b1) || (hi_c == 0u && blk == 0u))) continue;
+      const uint32_t r_hi = (hi_c == 0u) ? 0u : rank_at(hi_c);
+      const uint32_t r_lo = (hi_c == 0u) ? 0u : (lo_c < b0 ? rank_first : rank_at(min(lo_c, hi_c)));
+      DrawCmd c = p.cmd_template[m];
+      c.instanceCount = r_hi - r_lo;
+      c.firstInstance = p.first_instance + lo;
+      p.cmd_out[m] = c;
+    }
+  }
+
+  if (count_here == 0u) return;  // nothing visible in this block
+#pragma unroll
+  for (uint32_t k = 0; k < kPerLane; ++k) {
+    if ((word[k] >> lane) & 1ull) {
+      const uint32_t i = b0 + (k * 4u + wv) * 64u + lane;
+      const uint32_t g = sum_here + word_before[k] + rank_in(word[k]);
+      uint32_t base = lo_first, r = rank_first;
+      if (m_first != m_last) {
+        // largest m in [m_first, m_last] with mesh_base[m] <= i
+        uint32_t lo = m_first, hi = m_last;
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi + 1u) >> 1;
+          if (p.mesh_base[mid] <= i) lo = mid; else hi = mid - 1u;
+        }
+        if (lo != m_first) {
+          base = p.mesh_base[lo];
+          r = rank_at(min(max(base, b0), b1));
+        }
+      }
+      const uint32_t slot = base + (g - r);
+      if (slot < n) p.visible[slot] = p.first_instance + i;
+    }
+  }
+}
+
 }  // namespace
 
 uint64_t vkr_cull_workspace_size(uint64_t n, uint32_t m) {
   const uint64_t nblk = (n + kBlockInstances - 1) / kBlockInstances;
-  return align_up(nblk * kWordsPerBlock * 8, 256) + align_up(nblk * 4, 256) + 2 * align_up((nblk + 1) * 4, 256) +
+  return align_up(nblk * kWordsPerBlock * 8, 256) + 2 * align_up(nblk * 4, 256) + 2 * align_up((nblk + 1) * 4, 256) +
          align_up(((uint64_t)m + 1) * 4, 256) + align_up(nblk * kWordsPerBlock * 2, 256);
 }
 
@@ -373,7 +538,11 @@ hipError_t vkr_launch_cull_deterministic(const CullParams& p, hipStream_t stream
     return hipGetLastError();
   }
   hipLaunchKernelGGL(cull_mask_kernel, dim3(nblk), dim3(kBlockThreads), 0, stream, p);
-  hipLaunchKernelGGL(cull_scan_kernel, dim3(1), dim3(1024), 0, stream, p, nblk);
-  hipLaunchKernelGGL(cull_scatter_kernel, dim3(nblk), dim3(kBlockThreads), 0, stream, p);
+  if (nblk <= kPlaceMaxBlocks) {
+    hipLaunchKernelGGL(cull_place_kernel, dim3(nblk), dim3(kBlockThreads), 0, stream, p, nblk);
+  } else {
+    hipLaunchKernelGGL(cull_scan_kernel, dim3(1), dim3(1024), 0, stream, p, nblk);
+    hipLaunchKernelGGL(cull_scatter_kernel, dim3(nblk), dim3(kBlockThreads), 0, stream, p);
+  }
   return hipGetLastError();
 }
