@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--radius", type=float, default=25.0)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--flat", action="store_true", help="also time the untiled loop (slow: every light on every pixel)")
+    ap.add_argument("--scene", choices=("noise", "analytic"), default="noise",
+                    help="G-buffer: the synthetic one of the parity tests (depth uncorrelated between neighbouring pixels, so a "
+                         "tile spans hundreds of world units) or the analytic spheres-over-ground fill (coherent depth)")
     a = ap.parse_args()
     vkr = importlib.import_module("vk-renderer_amd")
     synth = importlib.import_module("vk-renderer_amd.synth")
@@ -31,10 +34,18 @@ def main():
     case = synth.deferred_case(a.width, a.height, a.lights, config_index=3)
     push = case["push"].copy()
     push[3] = a.radius
-    gb = vkr.GBuffer(ctx, a.width, a.height).upload(case["gbuf"])
+    gb = vkr.GBuffer(ctx, a.width, a.height)
+    if a.scene == "noise":
+        gb.upload(case["gbuf"])
+    else:
+        frame = importlib.import_module("vk-renderer_amd.frame")
+        cam = case["camera"]
+        spheres = ctx.buffer_from(synth.make_spheres(64))
+        frame.gbuffer_fill(ctx, gb, spheres, frame.make_gbuffer_scene(cam["vp"], cam["inv_vp"], cam["pos"], 64))
+        ctx.wait_idle()
     lights = ctx.buffer_from(case["lights"])
     out = ctx.image(vkr.FORMAT_R8G8B8A8_UNORM, a.width, a.height)
-    res = {"width": a.width, "height": a.height, "lights": a.lights, "radius": a.radius}
+    res = {"width": a.width, "height": a.height, "lights": a.lights, "radius": a.radius, "scene": a.scene}
     modes = [("tiled", vkr.DEFERRED_RADIUS_CUTOFF)]
     if a.flat:
         modes.append(("per_pixel_cutoff_whole_table", vkr.DEFERRED_RADIUS_CUTOFF | vkr.DEFERRED_NO_TILE_LISTS))
@@ -54,7 +65,8 @@ def main():
     if len(outs) == 2:
         res["identical"] = bool(np.array_equal(outs["tiled"], outs["per_pixel_cutoff_whole_table"]))
     # mean number of lights within the radius per pixel, from a sample of pixels (host, float64)
-    P = synth.unproject(case["camera"]["inv_vp"], a.width, a.height, case["gbuf"]["depth"])[::97, ::89].reshape(-1, 3)
+    depth = case["gbuf"]["depth"] if a.scene == "noise" else gb.depth.download(np.float32, 1)
+    P = synth.unproject(case["camera"]["inv_vp"], a.width, a.height, depth)[::97, ::89].reshape(-1, 3)
     lp = case["lights"][:, :3].astype(np.float64)
     d2 = ((P[:, None, :] - lp[None, :, :]) ** 2).sum(-1)
     res["mean_lights_in_radius_per_pixel"] = float((d2 < a.radius ** 2).sum(1).mean())

@@ -40,7 +40,13 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "vkr_kernels.h"
+
+#ifndef VKR_TILE_BATCH_FIRST
+#define VKR_TILE_BATCH_FIRST 8u
+#endif
 
 namespace {
 
@@ -53,6 +59,7 @@ constexpr float kInvDistFloor = 1e7f;      // 1 / kDistFloor
 constexpr float kStepScale = 0x1p100f;     // (c - 1e-6) * 2^100 saturates the clamp for any c > 1e-6
 constexpr float kRadiusStepScale = 0x1p80f;
 constexpr int kChunk = 512;                // lights per LDS chunk: 2 float4 each = 16 KiB
+constexpr int kTileSpan = 4096;            // tile light lists: lights tested per pass (64 groups of 64)
 
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -308,15 +315,15 @@ __device__ __forceinline__ uint32_t quantize_unorm8(float c) {
 // padded to an even count with a black light:
 //   kTile = false : the whole table, chunk after chunk;
 //   kTile = true  : (radius cutoff only) the lights whose sphere of influence reaches the tile's
-//                   world-space bounding box, appended in table order, 256 candidates per step.
+//                   world-space bounding box, in table order.
 // launch bound: 4 waves per SIMD (<= 128 VGPRs); measured 1-2 % faster than the 3 waves the allocator
-// settles on unprompted.
+// settles on unprompted.  The tile-list variants get 3 waves (<= 168 VGPRs): at 128 they spill some 30
+// registers, and a kernel that uses scratch memory at all measured 0.14 ms slower per 8K frame.
 template <int kOutMode, bool kRadius, bool kTile>
-__global__ __launch_bounds__(256, 4) void deferred_kernel(const DeferredParams p) {
+__global__ __launch_bounds__(256, kTile ? 3 : 4) void deferred_kernel(const DeferredParams p) {
   __shared__ float4 s_light[2 * kChunk + 4];  // +1 pair: the prefetch of the last iteration reads past the list
   __shared__ uint32_t s_stash[14][256];  // rows: see kRow* below
   __shared__ float s_red[8];
-  __shared__ uint32_t s_cnt[4];
   const uint32_t t = threadIdx.x;
   const uint32_t x0 = blockIdx.x * 32u + (t & 7u) * 4u;
   const uint32_t y = blockIdx.y * 32u + (t >> 3);
@@ -378,10 +385,9 @@ __global__ __launch_bounds__(256, 4) void deferred_kernel(const DeferredParams p
   // reach = radius + reconstruction pad.  Block-uniform, so it lives in LDS (broadcast reads) rather
   // than in 23 VGPRs of every lane.
   __shared__ float s_tile[23];
+  __shared__ uint64_t s_group_hits[kTileSpan / 64];        // kTile: ballot word of each 64-light group of the span
+  __shared__ uint32_t s_group_before[kTileSpan / 64 + 1];  // kTile: listed lights before each group
   if (kTile) {
-    float box_lo[3] = {0.0f, 0.0f, 0.0f}, box_hi[3] = {0.0f, 0.0f, 0.0f};
-    float face[4][4] = {};
-    float reach = 0.0f;
     float dmin = dmin_lane, dmax = dmax_lane;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -393,83 +399,134 @@ __global__ __launch_bounds__(256, 4) void deferred_kernel(const DeferredParams p
       s_red[4u + wv] = dmax;
     }
     __syncthreads();
-    dmin = fminf(fminf(s_red[0], s_red[1]), fminf(s_red[2], s_red[3]));
-    dmax = fmaxf(fmaxf(s_red[4], s_red[5]), fmaxf(s_red[6], s_red[7]));
-    // The pixel positions are the images of points of the clip-space box [xa,xb] x [ya,yb] x [dmin,dmax]
-    // under the projective map inverseVP; with w > 0 on all eight corners their hull contains them all.
-    const float xa = (float)(blockIdx.x * 32u) / (float)p.width * 2.0f - 1.0f;
-    const float xb = (float)min(blockIdx.x * 32u + 32u, p.width) / (float)p.width * 2.0f - 1.0f;
-    const float ya = (float)(blockIdx.y * 32u + p.row_offset) / (float)p.full_height * 2.0f - 1.0f;
-    const float yb = (float)(min(blockIdx.y * 32u + 32u, p.height) + p.row_offset) / (float)p.full_height * 2.0f - 1.0f;
-    const float* M = p.inv_vp;
-    bool sane = true;
-    auto unproject = [&](float cx, float cy, float cz, float (&q)[3]) {
-      const float wx = ((M[0] * cx + M[4] * cy) + M[8] * cz) + M[12];
-      const float wy = ((M[1] * cx + M[5] * cy) + M[9] * cz) + M[13];
-      const float wz = ((M[2] * cx + M[6] * cy) + M[10] * cz) + M[14];
-      const float ww = ((M[3] * cx + M[7] * cy) + M[11] * cz) + M[15];
-      q[0] = wx / ww;
-      q[1] = wy / ww;
-      q[2] = wz / ww;
-      sane = sane && (ww > 1e-30f) && (fabsf(q[0]) < 1e30f) && (fabsf(q[1]) < 1e30f) && (fabsf(q[2]) < 1e30f);
-    };
-    const float cxs[4] = {xa, xb, xb, xa}, cys[4] = {ya, ya, yb, yb};
-    float near_pt[4][3], ray_pt[4][3];
-    float scale = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float far_pt[3];
-      unproject(cxs[c], cys[c], dmin, near_pt[c]);
-      unproject(cxs[c], cys[c], dmax, far_pt);
-      unproject(cxs[c], cys[c], dmin - 0.25f, ray_pt[c]);  // a second point of the same pixel ray
+    if (wv == 0u) {  // block-uniform values: one wave computes them, the others wait at the barrier below
+      dmin = fminf(fminf(s_red[0], s_red[1]), fminf(s_red[2], s_red[3]));
+      dmax = fmaxf(fmaxf(s_red[4], s_red[5]), fmaxf(s_red[6], s_red[7]));
+      // The pixel positions are the images of points of the clip-space box [xa,xb] x [ya,yb] x [dmin,dmax]
+      // under the projective map inverseVP; with w > 0 on all eight corners their hull contains them all.
+      const float xa = (float)(blockIdx.x * 32u) / (float)p.width * 2.0f - 1.0f;
+      const float xb = (float)min(blockIdx.x * 32u + 32u, p.width) / (float)p.width * 2.0f - 1.0f;
+      const float ya = (float)(blockIdx.y * 32u + p.row_offset) / (float)p.full_height * 2.0f - 1.0f;
+      const float yb = (float)(min(blockIdx.y * 32u + 32u, p.height) + p.row_offset) / (float)p.full_height * 2.0f - 1.0f;
+      // Twelve points, one per lane: lane 4*kind + c holds corner c (xa ya, xb ya, xb yb, xa yb) at depth dmin
+      // (kind 0, the near points), dmax (kind 1, the far points) or dmin - 0.25 (kind 2, a second point of the
+      // same pixel ray).  Lanes from 12 up repeat them.
+      const uint32_t c = lane & 3u, kind = (lane >> 2) % 3u;
+      const float pcx = (c == 1u || c == 2u) ? xb : xa;
+      const float pcy = (c >= 2u) ? yb : ya;
+      const float pcz = kind == 0u ? dmin : (kind == 1u ? dmax : dmin - 0.25f);
+      const float* M = p.inv_vp;
+      const float wx = ((M[0] * pcx + M[4] * pcy) + M[8] * pcz) + M[12];
+      const float wy = ((M[1] * pcx + M[5] * pcy) + M[9] * pcz) + M[13];
+      const float wz = ((M[2] * pcx + M[6] * pcy) + M[10] * pcz) + M[14];
+      const float ww = ((M[3] * pcx + M[7] * pcy) + M[11] * pcz) + M[15];
+      const float q[3] = {wx / ww, wy / ww, wz / ww};
+      const bool ok = (ww > 1e-30f) && (fabsf(q[0]) < 1e30f) && (fabsf(q[1]) < 1e30f) && (fabsf(q[2]) < 1e30f);
+      const bool sane = (__ballot(ok) & 0xFFFull) == 0xFFFull;
+      // box over the near and far points: lanes 0..7, which the xor offsets 1, 2, 4 keep among themselves
+      float box_lo[3], box_hi[3];
+      float scale = 0.0f;
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        box_lo[a] = c == 0 ? fminf(near_pt[c][a], far_pt[a]) : fminf(box_lo[a], fminf(near_pt[c][a], far_pt[a]));
-        box_hi[a] = c == 0 ? fmaxf(near_pt[c][a], far_pt[a]) : fmaxf(box_hi[a], fmaxf(near_pt[c][a], far_pt[a]));
+        box_lo[a] = q[a];
+        box_hi[a] = q[a];
+#pragma unroll
+        for (int off = 1; off <= 4; off <<= 1) {
+          box_lo[a] = fminf(box_lo[a], __shfl_xor(box_lo[a], off));
+          box_hi[a] = fmaxf(box_hi[a], __shfl_xor(box_hi[a], off));
+        }
+        scale = fmaxf(scale, fmaxf(fabsf(box_lo[a]), fabsf(box_hi[a])));
       }
-    }
+      // binary32 reconstruction error of a position is ~2e-4 relative at the far end of the depth range
+      const float pad = 2e-3f * scale + 1e-2f;
+      // the four side faces of the tile's pyramid, face c in lane c: plane through rays c and c+1, normal pointing
+      // away from ray c+2
+      float near1[3], near2[3], ray[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) scale = fmaxf(scale, fmaxf(fabsf(box_lo[a]), fabsf(box_hi[a])));
-    // binary32 reconstruction error of a position is ~2e-4 relative at the far end of the depth range
-    const float pad = 2e-3f * scale + 1e-2f;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      box_lo[a] = sane ? box_lo[a] - pad : -INFINITY;
-      box_hi[a] = sane ? box_hi[a] + pad : INFINITY;
-    }
-    // the four side faces of the tile's pyramid: plane through rays c and c+1, normal pointing away from ray c+2
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int c1 = (c + 1) & 3, c2 = (c + 2) & 3;
-      const float ux = ray_pt[c][0] - near_pt[c][0], uy = ray_pt[c][1] - near_pt[c][1], uz = ray_pt[c][2] - near_pt[c][2];
-      const float vx = near_pt[c1][0] - near_pt[c][0], vy = near_pt[c1][1] - near_pt[c][1], vz = near_pt[c1][2] - near_pt[c][2];
+      for (int a = 0; a < 3; ++a) {
+        near1[a] = __shfl(q[a], (int)((lane + 1u) & 3u));
+        near2[a] = __shfl(q[a], (int)((lane + 2u) & 3u));
+        ray[a] = __shfl(q[a], (int)(8u + c));
+      }
+      const float ux = ray[0] - q[0], uy = ray[1] - q[1], uz = ray[2] - q[2];
+      const float vx = near1[0] - q[0], vy = near1[1] - q[1], vz = near1[2] - q[2];
       float nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
       const float len2 = nx * nx + ny * ny + nz * nz;
       const float inv = len2 > 0.0f ? rsq_(len2) : 0.0f;  // degenerate face: zero normal, never culls
       nx *= inv; ny *= inv; nz *= inv;
-      const float side = nx * (near_pt[c2][0] - near_pt[c][0]) + ny * (near_pt[c2][1] - near_pt[c][1]) + nz * (near_pt[c2][2] - near_pt[c][2]);
+      const float side = nx * (near2[0] - q[0]) + ny * (near2[1] - q[1]) + nz * (near2[2] - q[2]);
       const float flip = side > 0.0f ? -1.0f : 1.0f;
-      face[c][0] = sane ? flip * nx : 0.0f;
-      face[c][1] = sane ? flip * ny : 0.0f;
-      face[c][2] = sane ? flip * nz : 0.0f;
-      // signed distance of x to the face = dot(n, x) - dot(n, near_pt[c]); fold the radius and the pad into the offset
-      face[c][3] = -(face[c][0] * near_pt[c][0] + face[c][1] * near_pt[c][1] + face[c][2] * near_pt[c][2]);
-    }
-    reach = sqrt_(p.radius2) + pad;
-    if (t == 0u) {
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        s_tile[a] = box_lo[a];
-        s_tile[3 + a] = box_hi[a];
+      const float fx = sane ? flip * nx : 0.0f, fy = sane ? flip * ny : 0.0f, fz = sane ? flip * nz : 0.0f;
+      if (lane < 4u) {
+        s_tile[6u + 4u * lane + 0u] = fx;
+        s_tile[6u + 4u * lane + 1u] = fy;
+        s_tile[6u + 4u * lane + 2u] = fz;
+        // signed distance of x to the face = dot(n, x) - dot(n, near point c)
+        s_tile[6u + 4u * lane + 3u] = -(fx * q[0] + fy * q[1] + fz * q[2]);
       }
+      if (lane == 0u) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int a = 0; a < 4; ++a) s_tile[6 + 4 * c + a] = face[c][a];
-      s_tile[22] = reach;
+        for (int a = 0; a < 3; ++a) {
+          s_tile[a] = sane ? box_lo[a] - pad : -INFINITY;
+          s_tile[3 + a] = sane ? box_hi[a] + pad : INFINITY;
+        }
+        s_tile[22] = sqrt_(p.radius2) + pad;  // reach
+      }
     }
     __syncthreads();
   }
+
+  // kTile, pass 1 over the lights [span, span + kTileSpan): every wave tests its share of the span's 64-light
+  // groups against the tile bounds and leaves one ballot word per group in LDS - no barrier between groups -
+  // then one wave turns the popcounts into list offsets.
+  auto test_span = [&](uint32_t span, auto batch) {
+    constexpr uint32_t kBatch = decltype(batch)::value;  // groups a wave tests per trip: that many position loads in flight
+    const uint32_t span_lights = min((uint32_t)kTileSpan, L - span);
+    const uint32_t groups = (span_lights + 63u) >> 6;
+    const float reach = s_tile[22];
+    for (uint32_t grp0 = wv; grp0 < groups; grp0 += 4u * kBatch) {
+      float4 lp[kBatch];
+#pragma unroll
+      for (uint32_t u = 0; u < kBatch; ++u) {
+        const uint32_t i = span + (grp0 + 4u * u) * 64u + lane;
+        lp[u] = lights[3u * min(i, L - 1u)];
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < kBatch; ++u) {
+        const uint32_t grp = grp0 + 4u * u;
+        const uint32_t i = span + grp * 64u + lane;
+        const float dx = fmaxf(fmaxf(s_tile[0] - lp[u].x, lp[u].x - s_tile[3]), 0.0f);
+        const float dy = fmaxf(fmaxf(s_tile[1] - lp[u].y, lp[u].y - s_tile[4]), 0.0f);
+        const float dz = fmaxf(fmaxf(s_tile[2] - lp[u].z, lp[u].z - s_tile[5]), 0.0f);
+        bool hit = (i < L) & ((dx * dx + dy * dy + dz * dz) < p.radius2);  // NaN position: never contributes, never listed
+        if (__ballot(hit) != 0ull) {  // the box rejects most lights of most groups: one uniform branch skips the face tests
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {  // outside a side face by more than the radius: cannot reach any pixel of the tile
+            const float* f = &s_tile[6 + 4 * c];
+            hit &= !(((f[0] * lp[u].x + f[1] * lp[u].y) + f[2] * lp[u].z) + f[3] > reach);  // no short circuit: straight-line code
+          }
+        }
+        const uint64_t hits = __ballot(hit);
+        if (lane == 0u && grp < groups) s_group_hits[grp] = hits;
+      }
+    }
+    __syncthreads();
+    if (wv == 0u) {
+      const uint32_t mine = lane < groups ? (uint32_t)__popcll(s_group_hits[lane]) : 0u;
+      uint32_t incl = mine;
+#pragma unroll
+      for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+      }
+      s_group_before[lane + 1u] = incl;
+      if (lane == 0u) s_group_before[0] = 0u;
+    }
+    __syncthreads();
+  };
+  // The first span is tested before any per-pixel state exists (fewer live registers); with at most
+  // kTileSpan lights that is the only pass 1 of the workgroup, and both pixel pairs use its words.
+  if (kTile && L > 0u) test_span(0u, std::integral_constant<uint32_t, VKR_TILE_BATCH_FIRST>());
 
   bool list_complete = false;  // kTile: the list built for the first pixel pair holds every reaching light
   uint32_t list_count = 0;
@@ -532,60 +589,49 @@ __global__ __launch_bounds__(256, 4) void deferred_kernel(const DeferredParams p
       // the first pixel pair listed every reaching light without overflowing: the list is still in LDS
       if (wave_live && list_count > 0u) shade_list((list_count + 1u) & ~1u);
     } else {
-      uint32_t count = 0;  // records in the list (block-uniform)
-      bool flushed = false;
-      for (uint32_t base = 0; base < L; base += 256u) {
-        const uint32_t i = base + t;
-        float4 lp = black_pos, lc = black_col;
-        bool hit = false;
-        if (i < L) {
-          lp = lights[3u * i];
-          lc = lights[3u * i + 1u];
-          const float dx = fmaxf(fmaxf(s_tile[0] - lp.x, lp.x - s_tile[3]), 0.0f);
-          const float dy = fmaxf(fmaxf(s_tile[1] - lp.y, lp.y - s_tile[4]), 0.0f);
-          const float dz = fmaxf(fmaxf(s_tile[2] - lp.z, lp.z - s_tile[5]), 0.0f);
-          hit = (dx * dx + dy * dy + dz * dz) < p.radius2;  // NaN position: never contributes, never listed
-          const float reach = s_tile[22];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {  // outside a side face by more than the radius: cannot reach any pixel of the tile
-            const float* f = &s_tile[6 + 4 * c];
-            hit = hit && !(((f[0] * lp.x + f[1] * lp.y) + f[2] * lp.z) + f[3] > reach);
+      // Lights go through in spans of kTileSpan: pass 1 (test_span) leaves a ballot word and a list offset
+      // per 64-light group; in pass 2 the hit lanes copy their records to the offsets, which keeps table
+      // order (the float sums are order-sensitive).  A span with more hits than the list holds is shaded
+      // in several rounds of whole groups.
+      bool single_round = true;
+      for (uint32_t span = 0; span < L; span += kTileSpan) {
+        const uint32_t span_lights = min((uint32_t)kTileSpan, L - span);
+        const uint32_t groups = (span_lights + 63u) >> 6;
+        if (span != 0u || (g != 0 && L > (uint32_t)kTileSpan)) test_span(span, std::integral_constant<uint32_t, 4u>());
+        const uint32_t total = s_group_before[groups];
+        uint32_t first = 0;  // first group of the round (block-uniform, like everything steering the barriers below)
+        while (first < groups) {
+          const uint32_t before = s_group_before[first];
+          uint32_t end = groups;
+          if (total - before > (uint32_t)kChunk) {
+            end = first + 1u;  // one group always fits
+            while (s_group_before[end + 1u] - before <= (uint32_t)kChunk) ++end;
+            single_round = false;
           }
-        }
-        const uint64_t hits = __ballot(hit);
-        __syncthreads();  // s_cnt and the list are free: every wave is past its previous use of them
-        if (lane == 0u) s_cnt[wv] = (uint32_t)__popcll(hits);
-        __syncthreads();
-        const uint32_t c0 = s_cnt[0], c1 = s_cnt[1], c2 = s_cnt[2], c3 = s_cnt[3];
-        const uint32_t before = count + (wv > 0u ? c0 : 0u) + (wv > 1u ? c1 : 0u) + (wv > 2u ? c2 : 0u);
-        if (hit) {
-          const uint32_t slot = before + __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u));
-          s_light[2u * slot] = lp;
-          s_light[2u * slot + 1u] = lc;
-        }
-        count += (c0 + c1) + (c2 + c3);
-        if (count > (uint32_t)kChunk - 256u) {  // the next step might not fit: shade what is listed
-          if (t == 0u && (count & 1u)) {
-            s_light[2u * count] = black_pos;
-            s_light[2u * count + 1u] = black_col;
+          const uint32_t count = s_group_before[end] - before;
+          if (count > 0u) {
+            for (uint32_t grp = first + wv; grp < end; grp += 4u) {
+              const uint64_t hits = s_group_hits[grp];
+              if ((hits >> lane) & 1ull) {
+                const uint32_t i = span + grp * 64u + lane;
+                const uint32_t slot = s_group_before[grp] - before + __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u));
+                s_light[2u * slot] = lights[3u * i];
+                s_light[2u * slot + 1u] = lights[3u * i + 1u];
+              }
+            }
+            if (t == 0u && (count & 1u)) {
+              s_light[2u * count] = black_pos;
+              s_light[2u * count + 1u] = black_col;
+            }
+            __syncthreads();
+            if (wave_live) shade_list((count + 1u) & ~1u);
+            __syncthreads();  // everyone is done reading before the list is rebuilt (or reused)
           }
-          __syncthreads();
-          if (wave_live) shade_list((count + 1u) & ~1u);
-          count = 0;
-          flushed = true;
+          first = end;
         }
+        list_count = total;
       }
-      if (count > 0u) {
-        if (t == 0u && (count & 1u)) {
-          s_light[2u * count] = black_pos;
-          s_light[2u * count + 1u] = black_col;
-        }
-        __syncthreads();
-        if (wave_live) shade_list((count + 1u) & ~1u);
-      }
-      list_complete = !flushed;
-      list_count = count;
-      __syncthreads();  // everyone is done reading before the list is rebuilt (or reused)
+      list_complete = single_round && L <= (uint32_t)kTileSpan;
     }
     // results: the first pair's go to LDS (over the rows of the words just consumed) until the second
     // pair is done, so that each lane writes its four pixels with full-width stores
