@@ -2,7 +2,7 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p vk-renderer_amd/lib/variants
-COMMON="--offload-arch=gfx950 -fPIC -std=c++17 -fvisibility=hidden -I include -I vk-renderer_amd/csrc"
+COMMON="--offload-arch=gfx950 -fPIC -std=c++17 -fvisibility=hidden -fno-slp-vectorize -I include -I vk-renderer_amd/csrc"
 while [ $# -gt 0 ]; do
   name=$1; flags=$2; shift 2
   /opt/rocm/bin/hipcc -c ${CULL_SRC:-vk-renderer_amd/csrc/cull.hip} -o /tmp/cull_$name.o $COMMON -O3 -ffp-contract=off $flags

@@ -22,9 +22,9 @@ UNITS = [
     # -falign-loops=32: loop headers on 32-byte boundaries (harmless; the placement sensitivity once seen
     # here was the transcendental issue hazard that the kernel now avoids explicitly).
     ("deferred.hip", ["-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-falign-loops=32"]),
-    ("cull.hip", ["-O3", "-ffp-contract=off"]),
-    ("scene.hip", ["-O3", "-ffp-contract=off"]),
-    ("gbuffer.hip", ["-O3", "-ffp-contract=off"]),
+    ("cull.hip", ["-O3", "-ffp-contract=off", "-fno-slp-vectorize"]),
+    ("scene.hip", ["-O3", "-ffp-contract=off", "-fno-slp-vectorize"]),
+    ("gbuffer.hip", ["-O3", "-ffp-contract=off", "-fno-slp-vectorize"]),
     ("vkr_api.hip", ["-O2"]),
     ("vkr_host.hip", ["-O2", "-ffp-contract=off"]),
 ]

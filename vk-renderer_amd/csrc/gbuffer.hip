@@ -98,7 +98,7 @@ struct Hit {
 };
 
 __global__ __launch_bounds__(256) void gbuffer_fill_kernel(const FillParams p) {
-  __shared__ float4 s_sphere[kSphereChunk];  // centre.xyz, radius
+  __shared__ float4 s_sphere[kSphereChunk];  // camera - centre, |camera - centre|^2 - radius^2
   const uint32_t t = threadIdx.x;
   const uint32_t x0 = blockIdx.x * 32u + (t & 7u) * 4u;
   const uint32_t y = blockIdx.y * 32u + (t >> 3);
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void gbuffer_fill_kernel(const FillParams p) {
   const float* M = sc.inv_view_proj;
   const float cam[3] = {sc.camera_pos[0], sc.camera_pos[1], sc.camera_pos[2]};
 
-  float dir[4][3];
+  float dir[4][3], a[4];  // ray direction (far point - camera) and its squared length
   Hit hit[4];
   const float v = ((float)(y + p.row_offset) + 0.5f) / (float)p.full_height;
   const float cy = v * 2.0f - 1.0f;
@@ -125,24 +125,29 @@ __global__ __launch_bounds__(256) void gbuffer_fill_kernel(const FillParams p) {
     dir[i][2] = wz / ww - cam[2];
     hit[i].t = 1.0f;
     hit[i].what = -1;
+    a[i] = (dir[i][0] * dir[i][0] + dir[i][1] * dir[i][1]) + dir[i][2] * dir[i][2];
   }
 
   for (uint32_t base = 0; base < sc.sphere_count; base += kSphereChunk) {
     const uint32_t n = min((uint32_t)kSphereChunk, sc.sphere_count - base);
     __syncthreads();
-    if (t < n) s_sphere[t] = make_float4(p.spheres[base + t].center[0], p.spheres[base + t].center[1], p.spheres[base + t].center[2], p.spheres[base + t].radius);
+    if (t < n) {
+      // staged per sphere: camera - centre and |camera - centre|^2 - radius^2, the same for every pixel
+      const vkr_sphere& sp = p.spheres[base + t];
+      const float oc[3] = {cam[0] - sp.center[0], cam[1] - sp.center[1], cam[2] - sp.center[2]};
+      s_sphere[t] = make_float4(oc[0], oc[1], oc[2], ((oc[0] * oc[0] + oc[1] * oc[1]) + oc[2] * oc[2]) - sp.radius * sp.radius);
+    }
     __syncthreads();
+    float4 ahead = s_sphere[0];
     for (uint32_t s = 0; s < n; ++s) {
-      const float4 sp = s_sphere[s];
-      const float oc[3] = {cam[0] - sp.x, cam[1] - sp.y, cam[2] - sp.z};
-      const float c = ((oc[0] * oc[0] + oc[1] * oc[1]) + oc[2] * oc[2]) - sp.w * sp.w;
+      const float4 sp = ahead;
+      ahead = s_sphere[min(s + 1u, n - 1u)];  // requested before this sphere's arithmetic
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float a = (dir[i][0] * dir[i][0] + dir[i][1] * dir[i][1]) + dir[i][2] * dir[i][2];
-        const float b = (oc[0] * dir[i][0] + oc[1] * dir[i][1]) + oc[2] * dir[i][2];
-        const float disc = b * b - a * c;
+        const float b = (sp.x * dir[i][0] + sp.y * dir[i][1]) + sp.z * dir[i][2];
+        const float disc = b * b - a[i] * sp.w;
         if (disc >= 0.0f) {
-          const float tt = (-b - sqrtf(disc)) / a;
+          const float tt = (-b - sqrtf(disc)) / a[i];
           if (tt > 0.0f && tt < hit[i].t) {
             hit[i].t = tt;
             hit[i].what = (int32_t)(base + s);
