@@ -332,7 +332,7 @@ def main():
             call_ms = e1.elapsed_ms_since(e0) / K
             vis = int(css[0].results()["cmds"]["instanceCount"].sum())
             cb = cull_algorithmic(N, vis, M)
-            kernels = ("cull_init_cmds", "cull_atomic_kernel") if flags == 0 else ("cull_mask_kernel", "cull_scan_kernel", "cull_scatter_kernel")
+            kernels = ("cull_init_cmds", "cull_atomic_kernel") if flags == 0 else ("cull_mask_kernel", "cull_place_kernel")
             c_traffic = sum(pmc[k] for k in kernels) if default_workload and all(k in pmc for k in kernels) else None
             cull[mode_name] = {"value": float(N) * K * world / cw / 1e9, "unit": "G instances/s", "ms_per_call": call_ms,
                                "visible_fraction": vis / N,
