@@ -61,6 +61,17 @@ def test_rgba8_parity(vkr, synth, oracle, ctx, w, h, lights):
     _check_u8(got, o32, omx, f"{w}x{h} L={lights}")
 
 
+def test_reference_sized_frame_1080p_32_lights(vkr, synth, oracle, ctx):
+    """The reference's own runnable size (1920x1080, 32 point lights): the whole frame against both oracle
+    evaluations, in float and in the 8-bit format the reference writes."""
+    case = synth.deferred_case(1920, 1080, 32, config_index=0)
+    o32, omx = _oracles(oracle, case)
+    got, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT)
+    _check_float(got, o32, omx, "1920x1080 L=32")
+    got8, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R8G8B8A8_UNORM)
+    _check_u8(got8, o32, omx, "1920x1080 L=32")
+
+
 def test_rgba16f_output(vkr, synth, oracle, ctx):
     case = synth.deferred_case(64, 36, 13, config_index=5)
     _, omx = _oracles(oracle, case)
