@@ -111,7 +111,10 @@ typedef struct vkr_image2d {
 
 #define VKR_DEFERRED_RADIUS_CUTOFF 1u /* extension: a light contributes only where dist^2 < pointLightRadius^2
                                          (push[3]); enables per-tile light lists.  Off = reference behaviour
-                                         (pointLightRadius is pushed but never read, deferred.comp:8,120-129). */
+                                         (pointLightRadius is pushed but never read, deferred.comp:8,120-129).
+                                         From 256 lights up the call first lists the lights per 128 x 128 pixel bin
+                                         in context-owned device memory (4 bytes per bin and light; allocated or
+                                         grown inside the call, released with the context; skipped above 256 MiB). */
 #define VKR_DEFERRED_NO_TILE_LISTS 2u /* with RADIUS_CUTOFF: apply the cutoff per pixel only and loop over the whole
                                          light table (diagnostic; results are bit-identical to the tiled path) */
 

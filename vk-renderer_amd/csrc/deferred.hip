@@ -476,29 +476,35 @@ __global__ __launch_bounds__(256, kTile ? 3 : 4) void deferred_kernel(const Defe
     __syncthreads();
   }
 
-  // kTile, pass 1 over the lights [span, span + kTileSpan): every wave tests its share of the span's 64-light
+  // kTile: the candidates of this tile are the lights of its coarse bin when the launch carries bins, else
+  // the whole table; positions below index that candidate list.
+  const uint32_t bin_index = (blockIdx.y * 32u / kBinPixels) * p.bins_x + blockIdx.x * 32u / kBinPixels;
+  const uint32_t* __restrict__ bin = (kTile && p.bin_list) ? p.bin_list + (size_t)bin_index * L : nullptr;
+  const uint32_t LL = bin ? p.bin_count[bin_index] : L;
+
+  // kTile, pass 1 over the candidates [span, span + kTileSpan): every wave tests its share of the span's 64-light
   // groups against the tile bounds and leaves one ballot word per group in LDS - no barrier between groups -
   // then one wave turns the popcounts into list offsets.
   auto test_span = [&](uint32_t span, auto batch) {
     constexpr uint32_t kBatch = decltype(batch)::value;  // groups a wave tests per trip: that many position loads in flight
-    const uint32_t span_lights = min((uint32_t)kTileSpan, L - span);
+    const uint32_t span_lights = min((uint32_t)kTileSpan, LL - span);
     const uint32_t groups = (span_lights + 63u) >> 6;
     const float reach = s_tile[22];
     for (uint32_t grp0 = wv; grp0 < groups; grp0 += 4u * kBatch) {
       float4 lp[kBatch];
 #pragma unroll
       for (uint32_t u = 0; u < kBatch; ++u) {
-        const uint32_t i = span + (grp0 + 4u * u) * 64u + lane;
-        lp[u] = lights[3u * min(i, L - 1u)];
+        const uint32_t pos = min(span + (grp0 + 4u * u) * 64u + lane, LL - 1u);
+        lp[u] = lights[3u * (bin ? bin[pos] : pos)];
       }
 #pragma unroll
       for (uint32_t u = 0; u < kBatch; ++u) {
         const uint32_t grp = grp0 + 4u * u;
-        const uint32_t i = span + grp * 64u + lane;
+        const uint32_t pos = span + grp * 64u + lane;
         const float dx = fmaxf(fmaxf(s_tile[0] - lp[u].x, lp[u].x - s_tile[3]), 0.0f);
         const float dy = fmaxf(fmaxf(s_tile[1] - lp[u].y, lp[u].y - s_tile[4]), 0.0f);
         const float dz = fmaxf(fmaxf(s_tile[2] - lp[u].z, lp[u].z - s_tile[5]), 0.0f);
-        bool hit = (i < L) & ((dx * dx + dy * dy + dz * dz) < p.radius2);  // NaN position: never contributes, never listed
+        bool hit = (pos < LL) & ((dx * dx + dy * dy + dz * dz) < p.radius2);  // NaN position: never contributes, never listed
         if (__ballot(hit) != 0ull) {  // the box rejects most lights of most groups: one uniform branch skips the face tests
 #pragma unroll
           for (int c = 0; c < 4; ++c) {  // outside a side face by more than the radius: cannot reach any pixel of the tile
@@ -526,7 +532,7 @@ __global__ __launch_bounds__(256, kTile ? 3 : 4) void deferred_kernel(const Defe
   };
   // The first span is tested before any per-pixel state exists (fewer live registers); with at most
   // kTileSpan lights that is the only pass 1 of the workgroup, and both pixel pairs use its words.
-  if (kTile && L > 0u) test_span(0u, std::integral_constant<uint32_t, VKR_TILE_BATCH_FIRST>());
+  if (kTile && LL > 0u) test_span(0u, std::integral_constant<uint32_t, VKR_TILE_BATCH_FIRST>());
 
   bool list_complete = false;  // kTile: the list built for the first pixel pair holds every reaching light
   uint32_t list_count = 0;
@@ -594,10 +600,10 @@ __global__ __launch_bounds__(256, kTile ? 3 : 4) void deferred_kernel(const Defe
       // order (the float sums are order-sensitive).  A span with more hits than the list holds is shaded
       // in several rounds of whole groups.
       bool single_round = true;
-      for (uint32_t span = 0; span < L; span += kTileSpan) {
-        const uint32_t span_lights = min((uint32_t)kTileSpan, L - span);
+      for (uint32_t span = 0; span < LL; span += kTileSpan) {
+        const uint32_t span_lights = min((uint32_t)kTileSpan, LL - span);
         const uint32_t groups = (span_lights + 63u) >> 6;
-        if (span != 0u || (g != 0 && L > (uint32_t)kTileSpan)) test_span(span, std::integral_constant<uint32_t, 4u>());
+        if (span != 0u || (g != 0 && LL > (uint32_t)kTileSpan)) test_span(span, std::integral_constant<uint32_t, 4u>());
         const uint32_t total = s_group_before[groups];
         uint32_t first = 0;  // first group of the round (block-uniform, like everything steering the barriers below)
         while (first < groups) {
@@ -613,7 +619,8 @@ __global__ __launch_bounds__(256, kTile ? 3 : 4) void deferred_kernel(const Defe
             for (uint32_t grp = first + wv; grp < end; grp += 4u) {
               const uint64_t hits = s_group_hits[grp];
               if ((hits >> lane) & 1ull) {
-                const uint32_t i = span + grp * 64u + lane;
+                const uint32_t pos = span + grp * 64u + lane;
+                const uint32_t i = bin ? bin[pos] : pos;
                 const uint32_t slot = s_group_before[grp] - before + __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u));
                 s_light[2u * slot] = lights[3u * i];
                 s_light[2u * slot + 1u] = lights[3u * i + 1u];
@@ -631,7 +638,7 @@ __global__ __launch_bounds__(256, kTile ? 3 : 4) void deferred_kernel(const Defe
         }
         list_count = total;
       }
-      list_complete = single_round && L <= (uint32_t)kTileSpan;
+      list_complete = single_round && LL <= (uint32_t)kTileSpan;
     }
     // results: the first pair's go to LDS (over the rows of the words just consumed) until the second
     // pair is done, so that each lane writes its four pixels with full-width stores
@@ -719,6 +726,87 @@ __global__ void exact_div_check_kernel(uint32_t n, uint32_t seed, uint32_t* mism
   if (__float_as_uint(want) != __float_as_uint(got)) atomicAdd(mismatches, 1u);
 }
 
+// Coarse level of the tile light lists: one workgroup per kBinPixels x kBinPixels pixel bin lists, in table
+// order, the lights whose sphere of influence reaches the bin's view pyramid (four side planes through the
+// camera rays of the bin's corners; no depth bounds, so no G-buffer read).  A light is dropped only when it
+// lies outside a side plane by more than radius + pad, where pad covers the binary32 error of the pixel
+// positions it could light: those lie within the radius of the light, so their coordinates are bounded by
+// |light coordinate| + radius (same 2e-3 relative margin as the per-tile bounds).
+__global__ __launch_bounds__(256) void light_bins_kernel(const DeferredParams p, uint32_t* __restrict__ bin_list, uint32_t* __restrict__ bin_count) {
+  __shared__ float s_face[16];
+  __shared__ uint32_t s_cnt[4];
+  const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+  const uint32_t L = p.light_count;
+  if (wv == 0u) {
+    const uint32_t x0 = blockIdx.x * kBinPixels, y0 = blockIdx.y * kBinPixels;
+    const float xa = (float)x0 / (float)p.width * 2.0f - 1.0f;
+    const float xb = (float)min(x0 + kBinPixels, p.width) / (float)p.width * 2.0f - 1.0f;
+    const float ya = (float)(y0 + p.row_offset) / (float)p.full_height * 2.0f - 1.0f;
+    const float yb = (float)(min(y0 + kBinPixels, p.height) + p.row_offset) / (float)p.full_height * 2.0f - 1.0f;
+    // lane 4*kind + c: corner c (xa ya, xb ya, xb yb, xa yb) at two depths of the same pixel ray
+    const uint32_t c = lane & 3u, kind = (lane >> 2) & 1u;
+    const float pcx = (c == 1u || c == 2u) ? xb : xa;
+    const float pcy = (c >= 2u) ? yb : ya;
+    const float pcz = kind == 0u ? 0.99f : 0.5f;
+    const float* M = p.inv_vp;
+    const float wx = ((M[0] * pcx + M[4] * pcy) + M[8] * pcz) + M[12];
+    const float wy = ((M[1] * pcx + M[5] * pcy) + M[9] * pcz) + M[13];
+    const float wz = ((M[2] * pcx + M[6] * pcy) + M[10] * pcz) + M[14];
+    const float ww = ((M[3] * pcx + M[7] * pcy) + M[11] * pcz) + M[15];
+    const float q[3] = {wx / ww, wy / ww, wz / ww};
+    const bool ok = (ww > 1e-30f) && (fabsf(q[0]) < 1e30f) && (fabsf(q[1]) < 1e30f) && (fabsf(q[2]) < 1e30f);
+    const bool sane = (__ballot(ok) & 0xFFull) == 0xFFull;
+    float near1[3], near2[3], ray[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      near1[a] = __shfl(q[a], (int)((lane + 1u) & 3u));
+      near2[a] = __shfl(q[a], (int)((lane + 2u) & 3u));
+      ray[a] = __shfl(q[a], (int)(4u + c));
+    }
+    const float ux = ray[0] - q[0], uy = ray[1] - q[1], uz = ray[2] - q[2];
+    const float vx = near1[0] - q[0], vy = near1[1] - q[1], vz = near1[2] - q[2];
+    float nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
+    const float len2 = nx * nx + ny * ny + nz * nz;
+    const float inv = len2 > 0.0f ? rsq_(len2) : 0.0f;  // degenerate face: zero normal, never culls
+    nx *= inv; ny *= inv; nz *= inv;
+    const float side = nx * (near2[0] - q[0]) + ny * (near2[1] - q[1]) + nz * (near2[2] - q[2]);
+    const float flip = side > 0.0f ? -1.0f : 1.0f;
+    const float fx = sane ? flip * nx : 0.0f, fy = sane ? flip * ny : 0.0f, fz = sane ? flip * nz : 0.0f;
+    if (lane < 4u) {
+      s_face[4u * lane + 0u] = fx;
+      s_face[4u * lane + 1u] = fy;
+      s_face[4u * lane + 2u] = fz;
+      s_face[4u * lane + 3u] = -(fx * q[0] + fy * q[1] + fz * q[2]);
+    }
+  }
+  __syncthreads();
+  const float4* __restrict__ lights = reinterpret_cast<const float4*>(p.lights);
+  const uint32_t b = blockIdx.y * gridDim.x + blockIdx.x;
+  uint32_t* __restrict__ list = bin_list + (size_t)b * L;
+  const float radius = sqrt_(p.radius2);
+  uint32_t count = 0;  // block-uniform
+  for (uint32_t base = 0; base < L; base += 256u) {
+    const uint32_t i = base + t;
+    bool hit = i < L;
+    if (hit) {
+      const float4 lp = lights[3u * i];
+      const float scale = fmaxf(fmaxf(fabsf(lp.x), fabsf(lp.y)), fabsf(lp.z)) + radius;
+      const float reach = radius + (2e-3f * scale + 1e-2f);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) hit &= !(((s_face[4 * c] * lp.x + s_face[4 * c + 1] * lp.y) + s_face[4 * c + 2] * lp.z) + s_face[4 * c + 3] > reach);
+    }
+    const uint64_t hits = __ballot(hit);
+    __syncthreads();  // every wave is past its previous read of s_cnt
+    if (lane == 0u) s_cnt[wv] = (uint32_t)__popcll(hits);
+    __syncthreads();
+    const uint32_t c0 = s_cnt[0], c1 = s_cnt[1], c2 = s_cnt[2], c3 = s_cnt[3];
+    const uint32_t before = count + (wv > 0u ? c0 : 0u) + (wv > 1u ? c1 : 0u) + (wv > 2u ? c2 : 0u);
+    if (hit) list[before + __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u))] = i;
+    count += (c0 + c1) + (c2 + c3);
+  }
+  if (t == 0u) bin_count[b] = count;
+}
+
 template <int kOutMode>
 hipError_t launch_mode(const DeferredParams& p, hipStream_t stream) {
   const dim3 grid((p.width + 31u) / 32u, (p.height + 31u) / 32u, 1u);
@@ -732,6 +820,9 @@ hipError_t launch_mode(const DeferredParams& p, hipStream_t stream) {
   return hipGetLastError();
 }
 
+constexpr uint32_t kBinMinLights = 256;           // below this every tile tests the whole table: nothing to gain
+constexpr uint64_t kBinMaxEntries = 64ull << 20;  // 256 MiB of indices
+
 }  // namespace
 
 hipError_t vkr_launch_exact_div_check(uint32_t n, uint32_t seed, uint32_t* mismatches, hipStream_t stream) {
@@ -739,7 +830,28 @@ hipError_t vkr_launch_exact_div_check(uint32_t n, uint32_t seed, uint32_t* misma
   return hipGetLastError();
 }
 
-hipError_t vkr_launch_deferred(const DeferredParams& p, hipStream_t stream) {
+uint64_t vkr_deferred_bin_entries(const DeferredParams& p) {
+  const bool tiled = (p.flags & 1u) != 0u && (p.flags & 2u) == 0u;
+  if (!tiled || p.light_count < kBinMinLights) return 0;
+  const uint64_t bins = (uint64_t)((p.width + kBinPixels - 1u) / kBinPixels) * ((p.height + kBinPixels - 1u) / kBinPixels);
+  const uint64_t entries = bins * p.light_count;
+  return entries <= kBinMaxEntries ? entries : 0;
+}
+
+hipError_t vkr_launch_deferred(const DeferredParams& params, uint32_t* bins, hipStream_t stream) {
+  DeferredParams p = params;
+  p.bin_list = nullptr;
+  p.bin_count = nullptr;
+  p.bins_x = 0;
+  const uint64_t entries = vkr_deferred_bin_entries(p);
+  if (bins && entries != 0u) {
+    const dim3 bin_grid((p.width + kBinPixels - 1u) / kBinPixels, (p.height + kBinPixels - 1u) / kBinPixels, 1u);
+    hipLaunchKernelGGL(light_bins_kernel, bin_grid, dim3(256), 0, stream, p, bins, bins + entries);
+    if (hipError_t e = hipGetLastError()) return e;
+    p.bin_list = bins;
+    p.bin_count = bins + entries;
+    p.bins_x = bin_grid.x;
+  }
   switch (p.out_mode) {
     case kOutRgba8: return launch_mode<kOutRgba8>(p, stream);
     case kOutRgba16f: return launch_mode<kOutRgba16f>(p, stream);

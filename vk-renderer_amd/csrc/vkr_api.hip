@@ -186,7 +186,22 @@ int32_t run_deferred(vkr_context* ctx, const vkr_deferred_args* a) {
   p.radius2 = a->push[3] * a->push[3];
   std::memcpy(p.inv_vp, a->push + 4, 64);
   VKR_HIP(hipSetDevice(ctx->device));
-  VKR_HIP(vkr_launch_deferred(p, ctx->stream));
+  uint32_t* bins = nullptr;
+  const uint64_t bin_entries = vkr_deferred_bin_entries(p);
+  if (bin_entries != 0u) {
+    const uint32_t bin_count = ((w + kBinPixels - 1u) / kBinPixels) * ((h + kBinPixels - 1u) / kBinPixels);
+    const size_t need = (size_t)(bin_entries + bin_count) * sizeof(uint32_t);
+    if (need > ctx->light_bins_bytes) {
+      // hipFree waits for the device: earlier launches still reading the old bins finish first
+      if (ctx->light_bins) VKR_HIP(hipFree(ctx->light_bins));
+      ctx->light_bins = nullptr;
+      ctx->light_bins_bytes = 0;
+      VKR_HIP(hipMalloc(&ctx->light_bins, need));
+      ctx->light_bins_bytes = need;
+    }
+    bins = static_cast<uint32_t*>(ctx->light_bins);
+  }
+  VKR_HIP(vkr_launch_deferred(p, bins, ctx->stream));
   return VKR_OK;
 }
 
@@ -359,6 +374,7 @@ int32_t vkr_context_destroy(vkr_context* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamDestroy(ctx->stream);
   }
+  if (ctx->light_bins) (void)hipFree(ctx->light_bins);
   delete ctx;
   return VKR_OK;
 }

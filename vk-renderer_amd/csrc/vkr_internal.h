@@ -10,6 +10,8 @@ struct vkr_context {
   int device = 0;
   hipStream_t stream = nullptr;
   hipDeviceProp_t props{};
+  void* light_bins = nullptr;  // coarse light bins of the tiled resolve; grows on demand, freed with the context
+  size_t light_bins_bytes = 0;
 };
 
 // Records the message returned by vkr_last_error() for the calling thread and returns `code`.

@@ -25,9 +25,20 @@ struct DeferredParams {
   float cam[3];
   float radius2;
   float inv_vp[16];            // column-major
+  // Tile light lists, optional coarse level: for every kBinPixels x kBinPixels pixel bin the ascending
+  // indices of the lights whose sphere of influence can reach the bin's view pyramid.  bin_list == null:
+  // every tile tests the whole table.
+  const uint32_t* bin_list;    // bins_x * bins_y * light_count entries, bin-major
+  const uint32_t* bin_count;   // entries used per bin
+  uint32_t bins_x;
 };
 
-hipError_t vkr_launch_deferred(const DeferredParams& p, hipStream_t stream);
+constexpr uint32_t kBinPixels = 128;  // 4 x 4 tiles
+
+// Entries the coarse light bins of a launch need (0 when the launch does not use them).
+uint64_t vkr_deferred_bin_entries(const DeferredParams& p);
+// bins: device memory for vkr_deferred_bin_entries(p) + bins_x * bins_y uint32 words, or null.
+hipError_t vkr_launch_deferred(const DeferredParams& p, uint32_t* bins, hipStream_t stream);
 hipError_t vkr_launch_exact_div_check(uint32_t n, uint32_t seed, uint32_t* mismatches, hipStream_t stream);
 
 struct DrawCmd {
