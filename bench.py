@@ -114,6 +114,23 @@ def bench_callers(ctx, vkr, synth, args, K, WU, rank, world, barrier, pmc):
                                         "frac": flops / (ms * 1e-3) / VALU_FP32_PEAK, "traffic": pmc.get("gbuffer_fill_kernel"), "algorithmic_flops": flops,
                                         "algorithmic_bytes": byt, "hbm_frac": byt / (ms * 1e-3) / HBM_PEAK}}
 
+    # 8K x 4096 lights with the radius cutoff and tile light lists, on the analytic scene (coherent depth)
+    W8, H8, L8, R8 = 7680, 4320, 4096, 25.0
+    gb8 = vkr.GBuffer(ctx, W8, H8)
+    cam8 = synth.reference_camera(W8, H8)
+    frame.gbuffer_fill(ctx, gb8, sbuf, frame.make_gbuffer_scene(cam8["vp"], cam8["inv_vp"], cam8["pos"], 64))
+    case8 = synth.deferred_case(64, 36, L8, config_index=3)
+    push8 = case8["push"].copy()
+    push8[3] = R8
+    lights8 = ctx.buffer_from(case8["lights"])
+    out8 = ctx.image(vkr.FORMAT_R8G8B8A8_UNORM, W8, H8)
+    targs = vkr.make_deferred_args(gb8, out8, lights8, L8, push8, flags=vkr.DEFERRED_RADIUS_CUTOFF)
+    ms = timed(ctx, lambda: ctx.deferred_resolve(targs), K, WU)
+    out["tiled_resolve_8k"] = {"value": W8 * H8 / (ms * 1e-3) / 1e9, "unit": "Gpixel/s", "ms_per_call": ms, "lights": L8, "radius": R8,
+                               "workload": f"{W8}x{H8}, {L8} lights, radius cutoff {R8}, coarse bins + per-tile LDS light lists, analytic G-buffer",
+                               "hbm_frac": W8 * H8 * 24.0 / (ms * 1e-3) / HBM_PEAK}
+    del gb8, out8, lights8
+
     # camera path: 64 frames, each = cull of the N-instance set + analytic fill + resolve with L lights
     scene = synth.cull_case(N, M, config_index=2 + 10 * rank)
     cs = vkr.CullScene(ctx, scene["aabb_min"], scene["aabb_max"], scene["mesh_base"], scene["cmd_template"])
