@@ -538,9 +538,38 @@ __global__ __launch_bounds__(256, kTile ? 3 : 4) void deferred_kernel(const Defe
   uint32_t list_count = 0;
   float last[2][3] = {};  // float outputs: the second pair's colours
 
+  // results: the first pair's go to LDS (over the rows of the words just consumed) until the second
+  // pair is done, so that each lane writes its four pixels with full-width stores
+  auto keep_result = [&](int g, int i, const float (&rgb)[3]) {
+    if (kOutMode == kOutRgba8) {
+      s_stash[kRowAlbedo + g + i][t] = quantize_unorm8(rgb[0]) | (quantize_unorm8(rgb[1]) << 8) | (quantize_unorm8(rgb[2]) << 16) | 0xFF000000u;
+    } else if (g == 0) {
+      s_stash[kRowAlbedo + i][t] = __float_as_uint(rgb[0]);
+      s_stash[kRowMaterial + i][t] = __float_as_uint(rgb[1]);
+      s_stash[kRowExtra + i][t] = __float_as_uint(rgb[2]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) last[i][k] = rgb[k];
+    }
+  };
+
+  // kTile: no light reaches this tile (block-uniform; known after the only pass 1 when the candidates fit one
+  // span).  Every light sum of deferred.comp:120-129 is then zero and the pixel is its ambient term
+  // (deferred.comp:107), whatever its position and normal are: nothing of the per-pixel setup is needed.
+  const bool tile_dark = kTile && LL <= (uint32_t)kTileSpan && (LL == 0u || s_group_before[(LL + 63u) >> 6] == 0u);
+
   // One copy of the light loop serves both pixel pairs (no unrolling): half the code, same speed.
 #pragma unroll 1
   for (int g = 0; g < 4; g += 2) {
+    if (tile_dark) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const uint32_t albedo = s_stash[kRowAlbedo + g + i][t];
+        const float rgb[3] = {kAmbient * unorm8(albedo, 0), kAmbient * unorm8(albedo, 1), kAmbient * unorm8(albedo, 2)};
+        keep_result(g, i, rgb);
+      }
+      continue;
+    }
     Pixel s[2];
     if (g != 0) {
       mat[0] = s_stash[kRowMaterial + 2][t];
@@ -640,22 +669,11 @@ __global__ __launch_bounds__(256, kTile ? 3 : 4) void deferred_kernel(const Defe
       }
       list_complete = single_round && LL <= (uint32_t)kTileSpan;
     }
-    // results: the first pair's go to LDS (over the rows of the words just consumed) until the second
-    // pair is done, so that each lane writes its four pixels with full-width stores
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       float rgb[3];
       finish_pixel(s[i], s_stash[kRowAlbedo + g + i][t], s_stash[kRowMaterial + g + i][t], kRadius ? s[i].in_range > 0.0f : L > 0u, rgb);
-      if (kOutMode == kOutRgba8) {
-        s_stash[kRowAlbedo + g + i][t] = quantize_unorm8(rgb[0]) | (quantize_unorm8(rgb[1]) << 8) | (quantize_unorm8(rgb[2]) << 16) | 0xFF000000u;
-      } else if (g == 0) {
-        s_stash[kRowAlbedo + i][t] = __float_as_uint(rgb[0]);
-        s_stash[kRowMaterial + i][t] = __float_as_uint(rgb[1]);
-        s_stash[kRowExtra + i][t] = __float_as_uint(rgb[2]);
-      } else {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) last[i][k] = rgb[k];
-      }
+      keep_result(g, i, rgb);
     }
   }
   if (!inside) return;
