@@ -243,6 +243,35 @@ def test_fill_then_resolve_matches_oracle(vkr, ctx, synth, oracle, frame_mod):
     assert lit.max() > 40 and lit.std() > 5  # the lights really light the scene
 
 
+def test_full_8k_tiled_equals_whole_table_loop(vkr, ctx, synth, frame_mod):
+    """BASELINE size of the tiled configuration: 7680x4320, 4096 lights, radius cutoff, on the analytic scene.
+    The tile-list result (coarse bins, per-tile lists, ambient-only tiles) must be the bytes of the same kernel
+    looping over the whole table, for the whole frame and for a screen band of it."""
+    w, h, L = 7680, 4320, 4096
+    cam, spheres, sc = fill_case(vkr, synth, frame_mod, w, h, 64, 9)
+    gb = vkr.GBuffer(ctx, w, h)
+    sbuf = ctx.buffer_from(spheres)
+    frame_mod.gbuffer_fill(ctx, gb, sbuf, sc)
+    lights = synth.deferred_case(64, 36, L, config_index=3)["lights"]
+    lbuf = ctx.buffer_from(lights)
+    push = np.asarray(cam["push"], np.float32).copy()
+    push[3] = 25.0
+    out_t, out_f = ctx.image(vkr.FORMAT_R8G8B8A8_UNORM, w, h), ctx.image(vkr.FORMAT_R8G8B8A8_UNORM, w, h)
+    ctx.deferred_resolve(vkr.make_deferred_args(gb, out_t, lbuf, L, push, flags=vkr.DEFERRED_RADIUS_CUTOFF))
+    ctx.deferred_resolve(vkr.make_deferred_args(gb, out_f, lbuf, L, push, flags=vkr.DEFERRED_RADIUS_CUTOFF | vkr.DEFERRED_NO_TILE_LISTS))
+    ctx.wait_idle()
+    tiled, flat = out_t.download(np.uint8, 4), out_f.download(np.uint8, 4)
+    assert np.array_equal(tiled, flat)
+    ambient = np.rint(np.float32(0.05) * gb.albedo.download(np.uint8, 4)[..., :3].astype(np.float32)).astype(np.uint8)
+    lit = (tiled[..., :3] != ambient).any(-1)
+    assert 0.005 < lit.mean() < 0.9  # some of the frame is within reach of a light, most of it is not
+    r0, r1 = 1000, 1700
+    out_t.buffer.fill_u32(0)
+    ctx.deferred_resolve(vkr.make_deferred_args(gb, out_t, lbuf, L, push, flags=vkr.DEFERRED_RADIUS_CUTOFF, row0=r0, rows=r1 - r0))
+    ctx.wait_idle()
+    assert np.array_equal(out_t.download(np.uint8, 4)[r0:r1], flat[r0:r1])
+
+
 def test_frame_loop_camera_path(vkr, ctx, synth, oracle, frame_mod):
     """Eight frames of the camera path, three in flight: every retained output equals the oracle pipeline
     (oracle fill -> oracle resolve) for the camera of the frame that wrote it, within 1 LSB."""
