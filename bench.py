@@ -128,7 +128,8 @@ def bench_callers(ctx, vkr, synth, args, K, WU, rank, world, barrier, pmc):
     ms = timed(ctx, lambda: ctx.deferred_resolve(targs), K, WU)
     out["tiled_resolve_8k"] = {"value": W8 * H8 / (ms * 1e-3) / 1e9, "unit": "Gpixel/s", "ms_per_call": ms, "lights": L8, "radius": R8,
                                "workload": f"{W8}x{H8}, {L8} lights, radius cutoff {R8}, coarse bins + per-tile LDS light lists, analytic G-buffer",
-                               "hbm_frac": W8 * H8 * 24.0 / (ms * 1e-3) / HBM_PEAK}
+                               "hbm_frac": W8 * H8 * 24.0 / (ms * 1e-3) / HBM_PEAK, "algorithmic_bytes": W8 * H8 * 24.0,
+                               "traffic": pmc.get("deferred_kernel<0, true, true>")}
     del gb8, out8, lights8
 
     # camera path: 64 frames, each = cull of the N-instance set + analytic fill + resolve with L lights
