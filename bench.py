@@ -152,8 +152,10 @@ def bench_callers(ctx, vkr, synth, args, K, WU, rank, world, barrier, pmc):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: after an idle period the part needs about 12 launches of the 4K x 256 resolve (30 ms of load) to
+    # settle at its sustained clock - the first launch takes 3.6 ms, the thirteenth 2.4 ms
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=15)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--lights", type=int, default=256)
