@@ -379,6 +379,11 @@ def main():
         result["cpu_baseline"] = {"value": float(W) * rows / tc / 1e9, "unit": "Gpixel/s", "cores": cores, "kind": "port",
                                   "sample": f"rows 0..{rows} of the same {W}x{H} frame, {L} lights, binary32 C restatement of deferred.comp, {cores} threads",
                                   "seconds": tc}
+        rows1 = max(H // 16, 1)  # one thread on a sixteenth of the frame: about as long as the 16-thread run
+        tc0 = time.perf_counter()
+        oracle.deferred(case["gbuf"], case["lights"], case["push"], mode="f32", rows=(0, rows1), threads=1, want=("rgba8",))
+        tc1 = time.perf_counter() - tc0
+        result["cpu_baseline"]["one_core"] = {"value": float(W) * rows1 / tc1 / 1e9, "unit": "Gpixel/s", "sample": f"rows 0..{rows1}, 1 thread", "seconds": tc1}
         if not args.no_cull:
             sc = scenes[0]
             tc0 = time.perf_counter()
