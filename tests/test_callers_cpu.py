@@ -252,6 +252,36 @@ def test_fscene_parser_errors(vkr, frame_mod):
     assert st == vkr.ERR_OUT_OF_MEMORY and n.value == 6 and b"capacity" in vkr.lib().vkr_last_error()
 
 
+def test_fscene_parser_survives_hostile_documents(vkr, synth, frame_mod):
+    """Untrusted input: nesting far deeper than any scene file is rejected rather than followed down the call
+    stack, moderate nesting is accepted, and byte-level mutations of a valid document never crash the reader."""
+    with pytest.raises(vkr.VkrError, match="nesting"):
+        frame_mod.fscene_point_lights('{"a":' * 200000 + "1" + "}" * 200000)
+    with pytest.raises(vkr.VkrError, match="nesting"):
+        frame_mod.fscene_point_lights('{"lights": [], "x": ' + "[" * 300000 + "]" * 300000 + "}")
+    assert frame_mod.fscene_point_lights('{"x": ' + "[" * 200 + "]" * 200 + ', "lights": []}').shape == (0,)
+    base = synth.fscene_text(5, 3).encode()
+    rng = np.random.default_rng(5)
+    n = C.c_uint32()
+    out = np.zeros(16, vkr.LIGHT_INFO_DTYPE)
+    outcomes = set()
+    for _ in range(3000):
+        t = bytearray(base)
+        for _ in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(0, len(t)))
+            kind = int(rng.integers(0, 4))
+            if kind == 0:
+                t[pos] = int(rng.integers(0, 256))
+            elif kind == 1:
+                del t[pos:pos + int(rng.integers(1, 9))]
+            elif kind == 2:
+                t[pos:pos] = rng.choice([b"{", b"}", b"[", b"]", b",", b":", b'"', b"\\", b"1e999", b"\\u00", b"\x00"])
+            else:
+                del t[pos:]
+        outcomes.add(vkr.lib().vkr_fscene_point_lights(bytes(t), len(t), out.ctypes.data, 16, C.byref(n)))
+    assert outcomes <= {vkr.OK, vkr.ERR_INVALID_ARGUMENT, vkr.ERR_OUT_OF_MEMORY} and vkr.ERR_INVALID_ARGUMENT in outcomes
+
+
 def test_pack_point_lights_matches_oracle(vkr, oracle, frame_mod):
     rng = np.random.default_rng(11)
     n = 1000

@@ -102,11 +102,22 @@ struct Json {
     *out = v;
     return true;
   }
+  // Skipping recurses once per nesting level; documents nested deeper than any scene file are rejected
+  // instead of being followed down the call stack.
+  static constexpr int kMaxDepth = 256;
+  int depth = 0;
+  struct Level {
+    int& d;
+    explicit Level(int& depth) : d(depth) { ++d; }
+    ~Level() { --d; }
+  };
   bool skip() {  // any value
     ws();
     if (p >= end) return fail("unexpected end");
     if (*p == '"') return string(nullptr);
     if (*p == '{') {
+      const Level level(depth);
+      if (depth > kMaxDepth) return fail("nesting deeper than 256 levels");
       ++p;
       if (lit('}')) return true;
       do {
@@ -117,6 +128,8 @@ struct Json {
       return lit('}') || fail("expected '}'");
     }
     if (*p == '[') {
+      const Level level(depth);
+      if (depth > kMaxDepth) return fail("nesting deeper than 256 levels");
       ++p;
       if (lit(']')) return true;
       do {
