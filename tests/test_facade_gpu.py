@@ -10,7 +10,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BIN = os.path.join(ROOT, "tests", "cpp", "facade_frame")
+# VKR_TEST_BIN_DIR: another build of the two host programs (e.g. one with host sanitizers, beside its own library)
+BIN_DIR = os.environ.get("VKR_TEST_BIN_DIR", os.path.join(ROOT, "tests", "cpp"))
+BIN = os.path.join(BIN_DIR, "facade_frame")
 
 
 def test_cpp_facade_frame_loop(vkr, synth, oracle, tmp_path):
@@ -169,7 +171,7 @@ def test_cpp_camera_path(vkr, synth, oracle, tmp_path):
     constants, three command buffers in flight.  Checked against the oracle chain for the last three frames."""
     import importlib
     frame = importlib.import_module("vk-renderer_amd.frame")
-    exe = os.path.join(ROOT, "tests", "cpp", "camera_path")
+    exe = os.path.join(BIN_DIR, "camera_path")
     assert os.path.exists(exe), "tests/cpp/camera_path is built by __graft_entry__.build()"
     w, h, frames = 160, 90, 7
     d = str(tmp_path)
