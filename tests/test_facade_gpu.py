@@ -213,3 +213,17 @@ def test_cpp_camera_path(vkr, synth, oracle, tmp_path):
         nx = np.float32(xd)
         ocam.cursor_delta(float(nx - x), 0.0)
         x = nx
+
+
+def test_buffer_ranges_do_not_wrap(vkr, ctx):
+    """offset + size computed in 64 bits must not wrap past the buffer size check."""
+    buf = ctx.buffer(256)
+    host = np.zeros(16, np.uint8)
+    huge = (1 << 64) - 8
+    for call in (lambda: vkr.lib().vkr_buffer_upload(buf.handle, huge, host.ctypes.data, 16),
+                 lambda: vkr.lib().vkr_buffer_download(buf.handle, huge, host.ctypes.data, 16),
+                 lambda: vkr.lib().vkr_buffer_fill_u32(buf.handle, huge, 0, 16),
+                 lambda: vkr.lib().vkr_buffer_upload(buf.handle, 250, host.ctypes.data, 16)):
+        assert call() == vkr.ERR_INVALID_ARGUMENT
+    assert vkr.lib().vkr_buffer_upload(buf.handle, 240, host.ctypes.data, 16) == vkr.OK
+    ctx.wait_idle()

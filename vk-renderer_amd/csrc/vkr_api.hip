@@ -249,7 +249,7 @@ int32_t run_cull(vkr_context* ctx, const vkr_cull_args* a) {
 int32_t image_from_binding(const BoundImage& b, const char* what, vkr_image2d* out) {
   if (!b.buf) return fail(VKR_ERR_BAD_STATE, "dispatch: %s image not bound", what);
   const uint64_t need = (uint64_t)b.pitch * b.height;
-  if (b.offset + need > b.buf->bytes) return fail(VKR_ERR_INVALID_ARGUMENT, "dispatch: %s image exceeds its buffer", what);
+  if (b.offset > b.buf->bytes || need > b.buf->bytes - b.offset) return fail(VKR_ERR_INVALID_ARGUMENT, "dispatch: %s image exceeds its buffer", what);
   out->device = static_cast<uint8_t*>(b.buf->device) + b.offset;
   out->width = b.width;
   out->height = b.height;
@@ -260,7 +260,7 @@ int32_t image_from_binding(const BoundImage& b, const char* what, vkr_image2d* o
 
 int32_t buffer_ptr(const BoundBuffer& b, const char* what, uint64_t need, void** out) {
   if (!b.buf) return fail(VKR_ERR_BAD_STATE, "dispatch: %s buffer not bound", what);
-  if (b.offset + b.range > b.buf->bytes || b.range < need)
+  if (b.offset > b.buf->bytes || b.range > b.buf->bytes - b.offset || b.range < need)
     return fail(VKR_ERR_INVALID_ARGUMENT, "dispatch: %s buffer range %llu too small (need %llu)", what, (unsigned long long)b.range,
                 (unsigned long long)need);
   *out = static_cast<uint8_t*>(b.buf->device) + b.offset;
@@ -475,7 +475,7 @@ int32_t vkr_buffer_device_ptr(vkr_buffer* buf, void** out_device_ptr) {
 
 int32_t vkr_buffer_upload(vkr_buffer* buf, uint64_t offset, const void* src, uint64_t bytes) {
   if (!buf || (!src && bytes)) return fail(VKR_ERR_INVALID_ARGUMENT, "null argument");
-  if (offset + bytes > buf->bytes) return fail(VKR_ERR_INVALID_ARGUMENT, "upload of %llu bytes at %llu exceeds buffer size %llu", (unsigned long long)bytes, (unsigned long long)offset, (unsigned long long)buf->bytes);
+  if (offset > buf->bytes || bytes > buf->bytes - offset) return fail(VKR_ERR_INVALID_ARGUMENT, "upload of %llu bytes at %llu exceeds buffer size %llu", (unsigned long long)bytes, (unsigned long long)offset, (unsigned long long)buf->bytes);
   if (!bytes) return VKR_OK;
   VKR_HIP(hipSetDevice(buf->ctx->device));
   VKR_HIP(hipMemcpyAsync(static_cast<uint8_t*>(buf->device) + offset, src, bytes, hipMemcpyHostToDevice, buf->ctx->stream));
@@ -484,7 +484,7 @@ int32_t vkr_buffer_upload(vkr_buffer* buf, uint64_t offset, const void* src, uin
 
 int32_t vkr_buffer_download(vkr_buffer* buf, uint64_t offset, void* dst, uint64_t bytes) {
   if (!buf || (!dst && bytes)) return fail(VKR_ERR_INVALID_ARGUMENT, "null argument");
-  if (offset + bytes > buf->bytes) return fail(VKR_ERR_INVALID_ARGUMENT, "download of %llu bytes at %llu exceeds buffer size %llu", (unsigned long long)bytes, (unsigned long long)offset, (unsigned long long)buf->bytes);
+  if (offset > buf->bytes || bytes > buf->bytes - offset) return fail(VKR_ERR_INVALID_ARGUMENT, "download of %llu bytes at %llu exceeds buffer size %llu", (unsigned long long)bytes, (unsigned long long)offset, (unsigned long long)buf->bytes);
   if (!bytes) return VKR_OK;
   VKR_HIP(hipSetDevice(buf->ctx->device));
   VKR_HIP(hipMemcpyAsync(dst, static_cast<uint8_t*>(buf->device) + offset, bytes, hipMemcpyDeviceToHost, buf->ctx->stream));
@@ -495,7 +495,7 @@ int32_t vkr_buffer_download(vkr_buffer* buf, uint64_t offset, void* dst, uint64_
 int32_t vkr_buffer_fill_u32(vkr_buffer* buf, uint64_t offset, uint32_t value, uint64_t bytes) {
   if (!buf) return fail(VKR_ERR_INVALID_ARGUMENT, "null argument");
   if ((offset | bytes) & 3u) return fail(VKR_ERR_INVALID_ARGUMENT, "fill offset/size must be multiples of 4");
-  if (offset + bytes > buf->bytes) return fail(VKR_ERR_INVALID_ARGUMENT, "fill exceeds buffer size");
+  if (offset > buf->bytes || bytes > buf->bytes - offset) return fail(VKR_ERR_INVALID_ARGUMENT, "fill exceeds buffer size");
   if (!bytes) return VKR_OK;
   VKR_HIP(hipSetDevice(buf->ctx->device));
   VKR_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(static_cast<uint8_t*>(buf->device) + offset), (int)value, bytes / 4, buf->ctx->stream));
@@ -555,7 +555,7 @@ int32_t vkr_cmd_bind_buffer(vkr_cmd* cmd, uint32_t set, uint32_t binding, vkr_bu
   if (!cmd || !buf) return fail(VKR_ERR_INVALID_ARGUMENT, "null argument");
   if (cmd->ended) return fail(VKR_ERR_BAD_STATE, "command list already ended");
   if (set >= kMaxSets || binding >= kMaxBindings) return fail(VKR_ERR_INVALID_ARGUMENT, "set %u / binding %u out of range", set, binding);
-  if (offset + range > buf->bytes) return fail(VKR_ERR_INVALID_ARGUMENT, "buffer binding [%llu,%llu) exceeds buffer size %llu", (unsigned long long)offset, (unsigned long long)(offset + range), (unsigned long long)buf->bytes);
+  if (offset > buf->bytes || range > buf->bytes - offset) return fail(VKR_ERR_INVALID_ARGUMENT, "buffer binding [%llu,%llu) exceeds buffer size %llu", (unsigned long long)offset, (unsigned long long)(offset + range), (unsigned long long)buf->bytes);
   cmd->cur.buffers[set][binding] = {buf, offset, range};
   return VKR_OK;
 }
