@@ -294,6 +294,7 @@ void vkr_camera_default(vkr_camera* cam) {
 }
 
 void vkr_camera_view(const vkr_camera* cam, float out_view[16]) {
+  if (!cam || !out_view) return;
   const float center[3] = {cam->pos[0] + cam->forward[0], cam->pos[1] + cam->forward[1], cam->pos[2] + cam->forward[2]};
   vkrm::look_at(cam->pos, center, cam->up, out_view);
 }
@@ -353,6 +354,7 @@ int32_t vkr_frame_setup(const vkr_camera* cam, const float proj[16], vkr_frame_c
 
 void vkr_pack_point_lights(uint32_t count, const float* pos3, const float* intensity3, const float* direction3, const float* opening_angle_deg,
                            const float* penumbra_angle_deg, vkr_light_info* out) {
+  if (!pos3 || !intensity3 || !direction3 || !opening_angle_deg || !penumbra_angle_deg || !out) return;
   for (uint32_t i = 0; i < count; ++i)
     pack_one(pos3 + 3ull * i, intensity3 + 3ull * i, direction3 + 3ull * i, opening_angle_deg[i], penumbra_angle_deg[i], out + i);
 }
