@@ -264,3 +264,71 @@ def test_oracle_variants_agree_where_well_conditioned(oracle, synth):
     assert np.median(rel) < 1e-6
     assert (rel > 1e-4).mean() < 0.01
     assert np.abs(o32["rgba8"].astype(int) - omx["rgba8"].astype(int)).max() <= 1
+
+
+def shader_in_numpy(gbuf, lights, push):
+    """A second, independent reading of /root/reference/shaders/deferred.comp:98-131 (and the functions it calls,
+    :32-96) in binary64 numpy, vectorised over pixels - written from the GLSL, not from the C restatement."""
+    H, W = gbuf["depth"].shape
+    # literals of the shader are binary32 constants (glslang folds 1.0/1.51 in binary32 too)
+    f = lambda c: float(np.float32(c))
+    PI, AMBIENT, ALPHA_MIN, EARLY_OUT, DIST_MIN = f(3.14159), f(0.05), f(0.0064), f(1e-6), f(1e-7)
+    INV_151 = float(np.float32(1.0) / np.float32(1.51))
+    cam = push[:3].astype(np.float64)
+    inv_vp = push[4:20].astype(np.float64).reshape(4, 4).T  # column-major in memory
+    x, y = np.meshgrid(np.arange(W), np.arange(H))
+    uv = np.stack([(x + 0.5) / W, (y + 0.5) / H], -1)                                           # :99
+    clip = np.concatenate([uv * 2 - 1, gbuf["depth"].astype(np.float64)[..., None], np.ones((H, W, 1))], -1)  # :100-101
+    world = clip @ inv_vp.T                                                                     # :102
+    pos = world[..., :3] / world[..., 3:4]                                                      # :103
+    albedo = gbuf["albedo"][..., :3].astype(np.float64) / 255                                   # :105
+    color = AMBIENT * albedo                                                                       # :106-107
+    nrm = gbuf["normal"][..., :3].astype(np.float64)
+    n = -nrm / np.linalg.norm(nrm, axis=-1, keepdims=True)                                      # :108
+    material = gbuf["material"][..., :3].astype(np.float64) / 255                               # :109
+    rough, metal = material[..., 1:2], material[..., 2:3]                                       # :111-112
+    diffuse_color = albedo * (1 - metal)                                                        # :114
+    specular_color = albedo * metal                                                             # :115
+    alpha = np.maximum(rough * rough, ALPHA_MIN)                                                   # :116
+    v = cam - pos
+    v /= np.linalg.norm(v, axis=-1, keepdims=True)                                              # :118
+    dot = lambda a, b: (a * b).sum(-1, keepdims=True)
+    schlick = lambda f0, f90, c: f0 + (f90 - f0) * np.maximum(1 - c, 0) ** 5                    # :32-38
+    on_threshold = np.zeros((H, W), bool)
+    for rec in lights.astype(np.float64):                                                       # :120
+        l = rec[0:3] - pos                                                                      # :121
+        dist2 = np.maximum(dot(l, l), DIST_MIN)                                                     # :122
+        l = l / np.linalg.norm(l, axis=-1, keepdims=True)                                       # :123
+        li = rec[4:7] / dist2                                                                   # :125
+        v_n, l_n = dot(v, n), dot(l, n)
+        lit = np.minimum(v_n, l_n) > EARLY_OUT                                                       # :43, :84
+        on_threshold |= (np.abs(np.minimum(v_n, l_n) - EARLY_OUT) < 1e-9)[..., 0]
+        with np.errstate(all="ignore"):
+            h = v + l
+            h /= np.linalg.norm(h, axis=-1, keepdims=True)                                      # :46, :87
+            l_h = dot(v, h)                                                                     # :47 (sic: v)
+            f90 = 0.5 * rough + 2.0 * l_h * l_h * rough                                         # :48, :50
+            weight = (1 - rough + rough * INV_151) * schlick(1.0, f90, v_n) * schlick(1.0, f90, l_n)  # :49, :52-54
+            diff = PI * diffuse_color * l_n * weight                                       # :56
+            a2 = alpha * alpha                                                                  # :90
+            d = (a2 - 1.0) * dot(h, n) ** 2 + 1.0                                               # :60
+            ndf = a2 / (d * d * PI)                                                        # :61
+            lam = lambda c: 0.5 * (-1.0 + np.sqrt(1.0 + a2 + np.maximum(1.0 - c * c, 0) / (c * c)))  # :64-70 (c > 0 here)
+            g = 1.0 / ((lam(v_n) + 1.0) * (lam(l_n) + 1.0))                                     # :72-76
+            spec = schlick(specular_color, 1.0, dot(v, h)) * ndf * g * 0.25 / v_n               # :94-95
+        color = color + np.where(lit, li * diff, 0.0)                                           # :127
+        color = color + np.where(lit, li * spec, 0.0)                                           # :128
+    return color, on_threshold
+
+
+def test_oracle_agrees_with_an_independent_numpy_reading_of_the_shader(oracle, synth):
+    case = synth.deferred_case(48, 27, 20, config_index=9)
+    want, on_threshold = shader_in_numpy(case["gbuf"], case["lights"], case["push"])
+    got = oracle.deferred(case["gbuf"], case["lights"], case["push"], mode="f64", want=("f64",))
+    skip = on_threshold | got["near_threshold"].astype(bool)
+    assert skip.mean() < 0.01
+    err = np.abs(got["f64"][..., :3] - want) / np.maximum(np.abs(want), 1e-30)
+    err[skip] = 0
+    # two binary64 evaluations in different operation orders; D = a2/(d*d*PI) amplifies rounding near mirror peaks
+    assert err.max() < 1e-9, err.max()
+    assert np.all(got["f64"][..., 3] == 1.0)
