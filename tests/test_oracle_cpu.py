@@ -332,3 +332,28 @@ def test_oracle_agrees_with_an_independent_numpy_reading_of_the_shader(oracle, s
     # two binary64 evaluations in different operation orders; D = a2/(d*d*PI) amplifies rounding near mirror peaks
     assert err.max() < 1e-9, err.max()
     assert np.all(got["f64"][..., 3] == 1.0)
+
+
+def test_cull_oracle_agrees_with_an_independent_numpy_evaluation(oracle, synth):
+    """The cull rule in elementwise binary32 numpy (separate multiplies and adds, same association), the compaction
+    with boolean indexing: mask, per-mesh counts and the compacted lists must equal the sequential C code."""
+    for n, m, idx in ((20000, 37, 0), (65536, 16, 1)):
+        scene = synth.cull_case(n, m, config_index=idx) if idx == 0 else synth.make_adversarial_cull(n, synth.SEED_CULL + 99, synth.reference_camera(3840, 2160), m)
+        planes = (scene["planes"] if idx == 0 else synth.reference_camera(3840, 2160)["planes"]).astype(np.float32).reshape(6, 4)
+        mn, mx = scene["aabb_min"][:, :3], scene["aabb_max"][:, :3]
+        vis = np.ones(n, bool)
+        for nx, ny, nz, nw in planes:
+            px = mx[:, 0] if nx >= 0 else mn[:, 0]
+            py = mx[:, 1] if ny >= 0 else mn[:, 1]
+            pz = mx[:, 2] if nz >= 0 else mn[:, 2]
+            d = ((np.float32(nx) * px + np.float32(ny) * py) + np.float32(nz) * pz) + np.float32(nw)
+            assert d.dtype == np.float32
+            vis &= d >= 0
+        res = oracle.cull(scene["aabb_min"], scene["aabb_max"], planes, scene["mesh_base"], scene["cmd_template"])
+        assert np.array_equal(res["mask"].astype(bool), vis)
+        mesh = scene["aabb_min"][:, 3].view(np.uint32)
+        assert np.array_equal(res["cmds"]["instanceCount"], np.bincount(mesh[vis], minlength=m).astype(np.uint32))
+        assert np.array_equal(res["cmds"]["firstInstance"], scene["mesh_base"][:m])
+        for k in range(m):
+            b, c = int(scene["mesh_base"][k]), int(res["cmds"]["instanceCount"][k])
+            assert np.array_equal(res["visible"][b:b + c], np.flatnonzero(vis & (mesh == k)).astype(np.uint32))
