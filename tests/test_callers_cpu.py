@@ -161,6 +161,68 @@ def test_oracle_fill_known_answer(oracle, vkr, synth):
     assert np.allclose(world[:3] / world[3], [0, 3, 46], atol=2e-2)
 
 
+
+def test_oracle_scene_tables_agree_with_an_independent_walk(oracle, synth):
+    """The node walk and table building of vkmodel.cpp:55-111 written a second time in plain Python (explicit stack,
+    double-precision matrix products) on a random 60-node tree: visiting order, per-mesh instance lists, skipped
+    meshes, running index / vertex totals equal the C restatement; matrices agree to binary32 rounding."""
+    tree = synth.make_scene_tree(60, 11, seed=77)
+    nodes, meshes = tree["nodes"], tree["meshes"]
+    t = oracle.scene_tables(nodes, [(v, f, mat, int(flags == synth.MESH_VALID)) for v, f, mat, flags in meshes])
+    per_mesh = [[] for _ in meshes]
+    order = []
+    stack = [(0, np.eye(4))]
+    while stack:
+        node, parent = stack.pop()                                                     # :59-60
+        local = np.asarray(nodes[node][0], np.float64).reshape(4, 4)                   # rows a, b, c, d after the transpose of :65
+        world = parent @ local                                                         # :66
+        for m in nodes[node][2]:                                                       # :69-70
+            per_mesh[m].append(world)
+            order.append(m)
+        for c in nodes[node][1]:                                                       # :71-72
+            stack.append((c, world))
+    assert t["pairs_mesh"][:len(order)].tolist() == order and t["total_instances"] == len(order)
+    kept = [k for k, (v, f, mat, valid) in enumerate(meshes) if valid == synth.MESH_VALID]   # :91-93
+    assert t["source_mesh"].tolist() == kept
+    first_index = vertex_offset = base = 0
+    for k, m in enumerate(kept):
+        v, f, mat, _ = meshes[m]
+        assert t["draw_commands"][k].tolist() == (3 * f, len(per_mesh[m]), first_index, vertex_offset, 0)   # :96
+        assert t["mesh_info"][k].tolist() == [3 * f, first_index, vertex_offset, mat]                        # :95
+        assert t["per_mesh_data"][k].tolist() == [mat, base]                                               # :108
+        got = t["mesh_matrices"][base:base + len(per_mesh[m])].reshape(-1, 4, 4).transpose(0, 2, 1)       # column-major storage
+        if per_mesh[m]:
+            want = np.stack(per_mesh[m])
+            assert np.allclose(got, want, rtol=2e-5, atol=2e-5 * np.abs(want).max())
+        first_index += 3 * f
+        vertex_offset += v
+        base += len(per_mesh[m])
+    assert t["mesh_base"].tolist()[-1] == base
+
+
+def test_oracle_instance_aabbs_agree_with_numpy(oracle, synth):
+    """Eight corners in the order of vkmodel.cpp:172-173 under each model matrix, elementwise binary32 with the
+    association ((m0*x + m1*y) + m2*z) + m3: bit-identical minima / maxima and the mesh id in min.w."""
+    soup = synth.make_instance_soup(5000, 23)
+    mats = soup["mesh_matrices"].reshape(-1, 4, 4)  # column-major: mats[i, c, r]
+    base = soup["mesh_base"].astype(np.int64)
+    mesh_of = np.searchsorted(base[1:], np.arange(mats.shape[0]), side="right")
+    lo, hi = soup["mesh_aabb"].reshape(-1, 8)[mesh_of, 0:3], soup["mesh_aabb"].reshape(-1, 8)[mesh_of, 4:7]
+    corners = [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1), (1, 1, 1)]
+    mn = np.full((mats.shape[0], 3), np.inf, np.float32)
+    mx = np.full((mats.shape[0], 3), -np.inf, np.float32)
+    for sx, sy, sz in corners:
+        x, y, z = (hi if sx else lo)[:, 0], (hi if sy else lo)[:, 1], (hi if sz else lo)[:, 2]
+        for r in range(3):
+            w = ((mats[:, 0, r] * x + mats[:, 1, r] * y) + mats[:, 2, r] * z) + mats[:, 3, r]
+            assert w.dtype == np.float32
+            mn[:, r] = np.minimum(mn[:, r], w)
+            mx[:, r] = np.maximum(mx[:, r], w)
+    omn, omx = oracle.instance_aabbs(soup["mesh_matrices"], soup["mesh_base"], soup["mesh_aabb"])
+    assert omn[:, :3].tobytes() == mn.tobytes() and omx[:, :3].tobytes() == mx.tobytes()
+    assert np.array_equal(omn[:, 3].view(np.uint32), mesh_of.astype(np.uint32))
+
+
 # ------------------------------------------------------------------------------------------ product host code vs oracle
 
 @pytest.mark.parametrize("nodes,meshes,seed", [(1, 1, 1), (50, 12, 2), (400, 37, 3), (5, 0, 4)])
