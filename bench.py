@@ -70,10 +70,11 @@ def timed(ctx, fn, iters, warmup):
     return e1.elapsed_ms_since(e0) / iters
 
 
-def bench_callers(ctx, vkr, synth, args, K, WU, rank, world, barrier, pmc):
+def bench_callers(ctx, vkr, synth, vdist, args, K, WU, rank, world, barrier, max_over_ranks, pmc):
     """The steps before the two passes, each on the headline sizes: per-instance bounds (2^22 instances),
     G-buffer attachment encode and analytic fill (4K), and the 64-frame camera path (cull + fill + resolve
-    per frame, three frames in flight).  Per-rank figures; every rank runs the same work."""
+    per frame, three frames in flight).  Per-rank figures, every rank running the same work - except the camera path,
+    whose 64 frames are dealt out over the ranks (frame f on rank f % world)."""
     import ctypes as C
     frame = importlib.import_module("vk-renderer_amd.frame")
     W, H, L = args.width, args.height, args.lights
@@ -142,10 +143,13 @@ def bench_callers(ctx, vkr, synth, args, K, WU, rank, world, barrier, pmc):
     barrier()
     t0 = time.perf_counter()
     frames = 64
-    loop.run_path(camera, frames)
-    dt = time.perf_counter() - t0
-    out["camera_path"] = {"value": frames / dt, "unit": "frames/s", "ms_per_frame": dt / frames * 1e3, "frames": frames,
-                          "workload": f"per frame: cull {N} instances, analytic G-buffer fill {W}x{H}, resolve with {L} lights; 3 frames in flight"}
+    mine = vdist.frame_slices(frames, world, rank)  # frame f is rendered by rank f % world
+    loop.run_path(camera, frames, only=mine)
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    out["camera_path"] = {"value": frames / dt, "unit": "frames/s", "ms_per_frame": dt / len(mine) * 1e3, "frames": frames,
+                          "frames_per_rank": len(mine), "scaling": "strong",
+                          "workload": f"per frame: cull {N} instances, analytic G-buffer fill {W}x{H}, resolve with {L} lights; 3 frames in flight; frame f on rank f % {world}"}
     return out
 
 
@@ -365,7 +369,7 @@ def main():
 
     # ---------------------------------------------------------------- callers either side of the passes
     if not args.no_callers and not args.no_cull:
-        result["callers"] = bench_callers(ctx, vkr, synth, args, K, WU, rank, world, barrier, pmc if default_workload else {})
+        result["callers"] = bench_callers(ctx, vkr, synth, vdist, args, K, WU, rank, world, barrier, max_over_ranks, pmc if default_workload else {})
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1)
     if world == 1 and not args.no_cpu_baseline:

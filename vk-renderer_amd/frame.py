@@ -169,8 +169,11 @@ class FrameLoop:
         self.submitted += 1
         return slot
 
-    def run_path(self, camera: Camera, frames: int, forward_units: float = 0.5, yaw_degrees: float = 1.0):
-        for _ in range(frames):
-            self.submit(camera)
+    def run_path(self, camera: Camera, frames: int, forward_units: float = 0.5, yaw_degrees: float = 1.0, only=None):
+        """Walks the camera over `frames` frames.  only: the frame indices this process renders (frame-batch
+        sharding: every rank walks the same path and submits its own frames); None = all."""
+        for f in range(frames):
+            if only is None or f in only:
+                self.submit(camera)
             camera.step_path(forward_units, yaw_degrees)
         self.ctx.wait_idle()
