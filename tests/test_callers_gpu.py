@@ -310,6 +310,30 @@ def test_frame_loop_camera_path(vkr, ctx, synth, oracle, frame_mod):
     assert not np.array_equal(loop.outputs[0].download(np.uint8, 4), loop.outputs[1].download(np.uint8, 4))  # the camera moved
 
 
+def test_camera_path_frame_sharding(vkr, ctx, synth, frame_mod):
+    """Frame-batch sharding: a rank that renders frames f % 2 == 1 of a 6-frame path ends with the same images and the
+    same camera as the process that renders all six (its last three frames are 1, 3, 5; the full run keeps 3, 4, 5)."""
+    dist = __import__("importlib").import_module("vk-renderer_amd.dist")
+    w, h, L = 128, 72, 8
+    spheres = synth.make_spheres(12, 3)
+    lights = np.ascontiguousarray(synth.deferred_case(64, 36, L, config_index=5)["lights"], np.float32).reshape(-1, 12)
+
+    def run(only):
+        loop = frame_mod.FrameLoop(ctx, w, h, lights, spheres, None, frames_in_flight=3)
+        cam = frame_mod.Camera()
+        loop.run_path(cam, 6, only=only)
+        return [o.download(np.uint8, 4) for o in loop.outputs], np.concatenate([np.asarray(cam.pos), np.asarray(cam.forward), cam.view()])
+
+    full, cam_full = run(None)
+    mine = dist.frame_slices(6, 2, 1)
+    assert list(mine) == [1, 3, 5]
+    part, cam_part = run(mine)
+    assert np.array_equal(cam_full, cam_part)
+    # full run: frame f sits in slot f % 3 -> slots hold 3, 4, 5; sharded run: its k-th frame sits in slot k % 3 -> 1, 3, 5
+    assert np.array_equal(part[1], full[0]) and np.array_equal(part[2], full[2])
+    assert not np.array_equal(part[0], full[0])
+
+
 # ------------------------------------------------------------------------------------------ committed fixtures
 
 def test_golden_fixtures(vkr, ctx, scene_mod, frame_mod):
