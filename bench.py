@@ -70,7 +70,7 @@ def timed(ctx, fn, iters, warmup):
     return e1.elapsed_ms_since(e0) / iters
 
 
-def bench_callers(ctx, vkr, synth, vdist, args, K, WU, rank, world, barrier, max_over_ranks, pmc):
+def bench_callers(ctx, vkr, synth, vdist, args, K, WU, rank, world, barrier, max_over_ranks, band_bench, pmc):
     """The steps before the two passes, each on the headline sizes: per-instance bounds (2^22 instances),
     G-buffer attachment encode and analytic fill (4K), and the 64-frame camera path (cull + fill + resolve
     per frame, three frames in flight).  Per-rank figures, every rank running the same work - except the camera path,
@@ -131,6 +131,10 @@ def bench_callers(ctx, vkr, synth, vdist, args, K, WU, rank, world, barrier, max
                                "workload": f"{W8}x{H8}, {L8} lights, radius cutoff {R8}, coarse bins + per-tile LDS light lists, analytic G-buffer",
                                "hbm_frac": W8 * H8 * 24.0 / (ms * 1e-3) / HBM_PEAK, "algorithmic_bytes": W8 * H8 * 24.0,
                                "traffic": pmc.get("deferred_kernel<0, true, true>")}
+    if world > 1:  # the same 8K frame in screen bands, one band per rank, gathered
+        tb = band_bench(gb8, out8, lights8, L8, push8, vkr.DEFERRED_RADIUS_CUTOFF, W8, H8)
+        out["tiled_resolve_8k"]["band_sharded"] = {"value": float(W8) * H8 * K / tb / 1e9, "unit": "Gpixel/s", "ms_per_frame": tb / K * 1e3,
+                                                   "scaling": "strong", "collective": "all_gather_into_tensor of rgba8 bands (RCCL)"}
     del gb8, out8, lights8
 
     # camera path: 64 frames, each = cull of the N-instance set + analytic fill + resolve with L lights
@@ -294,18 +298,15 @@ def main():
         del sets[1:], cargs
 
     # ---------------------------------------------------------------- deferred: one frame in bands
-    if world > 1:
-        frame = synth.deferred_case(W, H, L, config_index=1)  # the same frame on every rank
-        gb.upload(frame["gbuf"])
-        lights.upload(frame["lights"])
-        r0, r1 = vdist.band_rows(H, world, rank)
-        rows_max = vdist.band_rows(H, world, 0)[1]
-        pitch = out.pitch
+    def band_bench(gbuf, out_img, lights_buf, n_lights, push, flags, width, height):
+        """Seconds for K steps of: this rank resolves its band of rows of ONE frame, then the bands are gathered."""
+        r0, r1 = vdist.band_rows(height, world, rank)
+        rows_max = vdist.band_rows(height, world, 0)[1]
+        pitch = out_img.pitch
         band_t = torch.zeros(rows_max * pitch, dtype=torch.uint8, device="cuda")
         full_t = torch.zeros(world * rows_max * pitch, dtype=torch.uint8, device=coll_device)
-        band_img = vkr.Image2D(band_t.data_ptr(), W, r1 - r0, pitch, vkr.FORMAT_R8G8B8A8_UNORM)
-        bargs = vkr.make_deferred_args(gb, out, lights, L, frame["push"], row0=r0, rows=r1 - r0)
-        bargs.out = band_img
+        bargs = vkr.make_deferred_args(gbuf, out_img, lights_buf, n_lights, push, flags=flags, row0=r0, rows=r1 - r0)
+        bargs.out = vkr.Image2D(band_t.data_ptr(), width, r1 - r0, pitch, vkr.FORMAT_R8G8B8A8_UNORM)
 
         def band_step():
             ctx.deferred_resolve(bargs)
@@ -321,7 +322,13 @@ def main():
             band_step()
         torch.cuda.synchronize()
         barrier()
-        tb = max_over_ranks(time.perf_counter() - tb0)
+        return max_over_ranks(time.perf_counter() - tb0)
+
+    if world > 1:
+        frame = synth.deferred_case(W, H, L, config_index=1)  # the same frame on every rank
+        gb.upload(frame["gbuf"])
+        lights.upload(frame["lights"])
+        tb = band_bench(gb, out, lights, L, frame["push"], 0, W, H)
         result["band_sharded"] = {"value": float(W) * H * K / tb / 1e9, "unit": "Gpixel/s", "ms_per_frame": tb / K * 1e3,
                                   "scaling": "strong", "collective": "all_gather_into_tensor of rgba8 bands (RCCL)"}
 
@@ -369,7 +376,7 @@ def main():
 
     # ---------------------------------------------------------------- callers either side of the passes
     if not args.no_callers and not args.no_cull:
-        result["callers"] = bench_callers(ctx, vkr, synth, vdist, args, K, WU, rank, world, barrier, max_over_ranks, pmc if default_workload else {})
+        result["callers"] = bench_callers(ctx, vkr, synth, vdist, args, K, WU, rank, world, barrier, max_over_ranks, band_bench, pmc if default_workload else {})
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1)
     if world == 1 and not args.no_cpu_baseline:
