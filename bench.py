@@ -372,6 +372,38 @@ def main():
                                             "algorithmic_bytes": cb}}
         cull["config"] = {"workload": f"frustum cull + compaction, {N} instance AABBs, {M} meshes, {nsets} rotating input sets",
                           "parallelism": f"replicated scene x{world}"}
+        if world > 1:
+            # ONE scene split into instance ranges on mesh boundaries, one range per rank; the only exchange is the
+            # gather of the per-mesh commands (20 bytes per mesh), the compacted lists stay where they were made
+            shared = synth.cull_case(N, M, config_index=2)
+            cuts = vdist.mesh_range_cuts(shared["mesh_base"], N, world)
+            m0, m1, i0, i1 = cuts[rank]
+            part = vkr.CullScene(ctx, shared["aabb_min"][i0:i1], shared["aabb_max"][i0:i1], shared["mesh_base"][m0:m1] - np.uint32(i0),
+                                 shared["cmd_template"][m0:m1], first_mesh=m0, first_instance=i0)
+            cap = max(max(c[1] - c[0] for c in cuts) * 20, 16)
+            mine_t = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+            all_t = torch.zeros(world * cap, dtype=torch.uint8, device=coll_device)
+            pargs = part.args(shared["planes"], 0)
+            pargs.cmd_out = mine_t.data_ptr()  # the commands of this rank's meshes land in the tensor that is gathered
+
+            def range_step():
+                ctx.prep_indirect(pargs)
+                ctx.wait_idle()
+                dist.all_gather_into_tensor(all_t, mine_t if backend == "nccl" else mine_t.cpu())
+
+            for _ in range(WU):
+                range_step()
+            torch.cuda.synchronize()
+            barrier()
+            r0_ = time.perf_counter()
+            for _ in range(K):
+                range_step()
+            torch.cuda.synchronize()
+            barrier()
+            rt = max_over_ranks(time.perf_counter() - r0_)
+            cull["range_sharded"] = {"value": float(N) * K / rt / 1e9, "unit": "G instances/s", "ms_per_call": rt / K * 1e3, "scaling": "strong",
+                                     "collective": "all_gather_into_tensor of the per-mesh commands (RCCL)",
+                                     "ranges": [[int(c[2]), int(c[3])] for c in cuts]}
         result["cull"] = cull
 
     # ---------------------------------------------------------------- callers either side of the passes
