@@ -225,3 +225,36 @@ def test_cull_object_code_has_no_float_fma():
     assert re.search(r"v_(pk_)?mul_f32", asm) and re.search(r"v_(pk_)?add_f32", asm)
     fused = re.findall(r"\bv_(?:fma|fmac|mad|mac|pk_fma)_(?:f32|legacy_f32|f16)\w*", asm)
     assert fused == [], f"fused multiply-add in cull code: {set(fused)}"
+
+
+def test_resolve_kernels_use_no_scratch_memory():
+    """The resolve variants that production paths launch (plain and tile-list, every output format) must keep all
+    their state in registers and LDS: a spilled register is HBM traffic of the order of the output itself (an earlier
+    build wrote 61 MB per 4K frame instead of 33 MB because of four spilled registers)."""
+    obj = os.path.join(ROOT, "vk-renderer_amd", "lib", "deferred.o")
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
+    if not (os.path.exists(obj) and all(os.path.exists(t) for t in tools)):
+        pytest.skip("object file or LLVM tools not present")
+    tmp = os.environ.get("TMPDIR", "/tmp")
+    fat, co = os.path.join(tmp, "vkr_deferred_fat.bin"), os.path.join(tmp, "vkr_deferred_gfx950.co")
+    subprocess.run([tools[0], f"--dump-section=.hip_fatbin={fat}", obj], check=True, capture_output=True)
+    subprocess.run([tools[1], "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}"],
+                   check=True, capture_output=True)
+    notes = subprocess.run([tools[2], "--notes", co], capture_output=True, text=True, check=True).stdout
+    kernels = {}
+    for block in notes.split("- .agpr_count")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        kernels[name] = {k: int(re.search(rf"\.{k}:\s+(\d+)", block).group(1)) for k in ("private_segment_fixed_size", "vgpr_spill_count", "vgpr_count")}
+    checked = 0
+    for name, k in kernels.items():
+        m = re.search(r"deferred_kernelILi(\d)ELb([01])ELb([01])E", name)
+        if not m:
+            continue
+        radius, tile = m.group(2) == "1", m.group(3) == "1"
+        if radius and not tile:
+            continue  # the whole-table loop with the cutoff is a diagnostic, not a production path
+        assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0, (name, k)
+        assert k["vgpr_count"] <= (168 if tile else 128), (name, k)
+        checked += 1
+    assert checked == 6

@@ -553,11 +553,12 @@ __global__ __launch_bounds__(256, kTile ? 3 : 4) void deferred_kernel(const Defe
     }
   };
 
-  // No light at all, or (kTile) none that reaches this tile - block-uniform, known after the only pass 1 when
-  // the candidates fit one span.  Every light sum of deferred.comp:120-129 is then zero and the pixel is its
-  // ambient term (deferred.comp:107), whatever its position and normal are: nothing of the per-pixel setup is
-  // needed.
-  const bool tile_dark = L == 0u || (kTile && LL <= (uint32_t)kTileSpan && (LL == 0u || s_group_before[(LL + 63u) >> 6] == 0u));
+  // kTile: no light reaches this tile (block-uniform; known after the only pass 1 when the candidates fit one
+  // span).  Every light sum of deferred.comp:120-129 is then zero and the pixel is its ambient term
+  // (deferred.comp:107), whatever its position and normal are: nothing of the per-pixel setup is needed.
+  // (Only the tile-list variants take this path: as a run-time test in the other variants, for a table of
+  // zero lights, it costs them four spilled registers.)
+  const bool tile_dark = kTile && LL <= (uint32_t)kTileSpan && (LL == 0u || s_group_before[(LL + 63u) >> 6] == 0u);
 
   // One copy of the light loop serves both pixel pairs (no unrolling): half the code, same speed.
 #pragma unroll 1
