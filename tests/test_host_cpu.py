@@ -258,3 +258,24 @@ def test_resolve_kernels_use_no_scratch_memory():
         assert k["vgpr_count"] <= (168 if tile else 128), (name, k)
         checked += 1
     assert checked == 6
+
+
+@pytest.mark.parametrize("unit", ["cull", "scene", "gbuffer"])
+def test_other_kernels_use_no_scratch_memory(unit):
+    obj = os.path.join(ROOT, "vk-renderer_amd", "lib", unit + ".o")
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
+    if not (os.path.exists(obj) and all(os.path.exists(t) for t in tools)):
+        pytest.skip("object file or LLVM tools not present")
+    tmp = os.environ.get("TMPDIR", "/tmp")
+    fat, co = os.path.join(tmp, f"vkr_{unit}_fat.bin"), os.path.join(tmp, f"vkr_{unit}_gfx950.co")
+    subprocess.run([tools[0], f"--dump-section=.hip_fatbin={fat}", obj], check=True, capture_output=True)
+    subprocess.run([tools[1], "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}"],
+                   check=True, capture_output=True)
+    notes = subprocess.run([tools[2], "--notes", co], capture_output=True, text=True, check=True).stdout
+    blocks = notes.split("- .agpr_count")[1:]
+    assert blocks
+    for block in blocks:
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", block).group(1)) == 0, name
+        assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", block).group(1)) == 0, name
