@@ -185,6 +185,21 @@ typedef struct vkr_cull_args {
 VKR_API int32_t vkr_prep_indirect(vkr_context* ctx, const vkr_cull_args* args);
 VKR_API uint64_t vkr_cull_workspace_bytes(uint64_t instance_count, uint32_t mesh_count);
 
+/* No counterpart in the reference.  For callers that cannot allocate device memory or let a library do it
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the deterministic
+ * cull (visible[] ascending inside each mesh segment, as with VKR_CULL_DETERMINISTIC) with its workspace in
+ * a fixed array that is part of the library's GPU code (about 0.94 MiB per GPU, held until the process ends;
+ * its address is resolved once per GPU inside vkr_context_create).  Same arguments and results as
+ * vkr_prep_indirect; args->workspace / workspace_bytes are ignored and VKR_CULL_DETERMINISTIC is implied.
+ * The call makes no hipMalloc / hipFree or other allocating call.  VKR_ERR_INVALID_ARGUMENT if
+ * instance_count > VKR_NOALLOC_MAX_INSTANCES or mesh_count > VKR_NOALLOC_MAX_MESHES.
+ * All calls on one GPU share the one array: two calls whose kernels could overlap on a GPU (different
+ * contexts or processes' threads on the same device) race; calls on one context are stream-ordered and safe.
+ * Nothing in the array has to start at zero: every word a call reads was written by that call. */
+#define VKR_NOALLOC_MAX_INSTANCES 4194304ull /* 2^22 */
+#define VKR_NOALLOC_MAX_MESHES 65536u
+VKR_API int32_t vkr_prep_indirect_noalloc(vkr_context* ctx, const vkr_cull_args* args);
+
 /* ------------------------------------------------------------------ dispatch surface
  * Replaces the objects a caller of the reference touches to run a compute pass:
  * vw::Shader/loadShader (/root/reference/inc/vkshader.hpp:9-37) -> kernel looked up by name;

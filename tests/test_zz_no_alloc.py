@@ -1,0 +1,84 @@
+"""The entry point that allocates nothing, vkr_prep_indirect_noalloc, against the existing deterministic entry
+point (vkr_prep_indirect with VKR_CULL_DETERMINISTIC and a caller-provided workspace), through the C ABI.
+Bar: bit-exact - command buffer byte for byte, compacted list word for word (slots past each mesh's count
+included: neither call writes them), error flag.  Two calls in a row share the library's one static
+workspace per GPU, the second on a smaller input, so anything the larger call left behind would show."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(vkr, ctx, scene, planes, **kw):
+    """(results of the existing entry point, results of the allocation-free one) on the same device inputs."""
+    cs = vkr.CullScene(ctx, scene["aabb_min"], scene["aabb_max"], scene["mesh_base"], scene["cmd_template"], **kw)
+    out = []
+    for noalloc in (False, True):
+        cs.visible.fill_u32(0xFFFFFFFF)
+        cs.cmd_out.fill_u32(0xDEADBEEF, 0, cs.m * 20 // 4 * 4)
+        cs.error_flag.fill_u32(0)
+        if noalloc:
+            a = cs.args(planes, 0)          # VKR_CULL_DETERMINISTIC is implied
+            a.workspace, a.workspace_bytes = None, 0  # and the workspace arguments are ignored
+            ctx.prep_indirect_noalloc(a)
+        else:
+            ctx.prep_indirect(cs.args(planes, vkr.CULL_DETERMINISTIC))
+        ctx.wait_idle()
+        out.append(cs.results())
+    return out
+
+
+def _same(a, b):
+    assert a["error"] == b["error"] == 0
+    assert a["cmds"].tobytes() == b["cmds"].tobytes(), "indirect command buffer differs"
+    assert np.array_equal(a["visible"], b["visible"]), "compacted list differs"
+
+
+def test_two_calls_in_a_row_second_smaller(vkr, synth, oracle, ctx):
+    big = synth.cull_case(100000, 37, config_index=6)
+    small = synth.cull_case(5000, 9, config_index=7)
+    for scene in (big, small):
+        want, got = _both(vkr, ctx, scene, scene["planes"])
+        _same(want, got)
+        ref = oracle.cull(scene["aabb_min"], scene["aabb_max"], scene["planes"], scene["mesh_base"], scene["cmd_template"])
+        assert got["cmds"].tobytes() == ref["cmds"].tobytes()
+        assert np.array_equal(got["visible"], ref["visible"])
+        assert 0 < int(ref["mask"].sum()) < scene["aabb_min"].shape[0]
+
+
+def test_largest_accepted_size_then_a_ragged_one(vkr, synth, ctx):
+    n = vkr.NOALLOC_MAX_INSTANCES
+    scene = synth.cull_case(n, 1024, config_index=2)
+    want, got = _both(vkr, ctx, scene, scene["planes"])
+    _same(want, got)
+    assert 0.05 < int(got["cmds"]["instanceCount"].sum()) / n < 0.5
+    ragged = synth.cull_case(1025, 5, config_index=3)
+    want, got = _both(vkr, ctx, ragged, ragged["planes"])
+    _same(want, got)
+
+
+def test_instance_range_arguments(vkr, synth, ctx):
+    """first_mesh / first_instance behave as in the existing entry point."""
+    scene = synth.cull_case(50000, 64, config_index=5)
+    m0, i0 = 29, int(scene["mesh_base"][29])
+    part = {"aabb_min": scene["aabb_min"][i0:], "aabb_max": scene["aabb_max"][i0:],
+            "mesh_base": scene["mesh_base"][m0:] - np.uint32(i0), "cmd_template": scene["cmd_template"][m0:]}
+    want, got = _both(vkr, ctx, part, scene["planes"], first_mesh=m0, first_instance=i0)
+    _same(want, got)
+
+
+def test_rejects_sizes_beyond_the_static_workspace(vkr, synth, ctx):
+    scene = synth.cull_case(100, 4)
+    cs = vkr.CullScene(ctx, scene["aabb_min"], scene["aabb_max"], scene["mesh_base"], scene["cmd_template"])
+    a = cs.args(scene["planes"], 0)
+    a.instance_count = vkr.NOALLOC_MAX_INSTANCES + 1
+    with pytest.raises(vkr.VkrError, match="exceed the limit"):
+        ctx.prep_indirect_noalloc(a)
+    a = cs.args(scene["planes"], 0)
+    a.mesh_count = vkr.NOALLOC_MAX_MESHES + 1
+    with pytest.raises(vkr.VkrError, match="exceed the limit"):
+        ctx.prep_indirect_noalloc(a)
+    # an unchanged small call still works afterwards
+    ctx.prep_indirect_noalloc(cs.args(scene["planes"], 0))
+    ctx.wait_idle()
+    assert cs.results()["error"] == 0

@@ -30,6 +30,8 @@ BUFFER_DEVICE, BUFFER_HOST_VISIBLE = 0, 1
 DEFERRED_RADIUS_CUTOFF = 1
 DEFERRED_NO_TILE_LISTS = 2
 CULL_DETERMINISTIC = 1
+NOALLOC_MAX_INSTANCES = 1 << 22
+NOALLOC_MAX_MESHES = 1 << 16
 LIGHT_STRIDE = 48
 
 DRAW_CMD_DTYPE = np.dtype([("indexCount", "<u4"), ("instanceCount", "<u4"), ("firstIndex", "<u4"),
@@ -142,6 +144,7 @@ EXPORTS = {
     "vkr_deferred_resolve": (C.c_int32, [_P, C.POINTER(DeferredArgs)]),
     "vkr_prep_indirect": (C.c_int32, [_P, C.POINTER(CullArgs)]),
     "vkr_cull_workspace_bytes": (C.c_uint64, [C.c_uint64, C.c_uint32]),
+    "vkr_prep_indirect_noalloc": (C.c_int32, [_P, C.POINTER(CullArgs)]),
     "vkr_kernel_get": (C.c_int32, [_P, C.c_char_p, _PP]),
     "vkr_kernel_push_constant_size": (C.c_int32, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "vkr_cmd_begin": (C.c_int32, [_P, _PP]),
@@ -428,6 +431,10 @@ class Context:
 
     def prep_indirect(self, args: CullArgs):
         _check(lib().vkr_prep_indirect(self.handle, C.byref(args)))
+
+    def prep_indirect_noalloc(self, args: CullArgs):
+        """The deterministic cull in the library's static per-GPU workspace: no allocation inside the call."""
+        _check(lib().vkr_prep_indirect_noalloc(self.handle, C.byref(args)))
 
     def destroy(self):
         if self.handle:

@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "vkr_kernels.h"
 
 #ifndef VKR_ATOMIC_PER_LANE
@@ -181,7 +183,7 @@ struct DetWorkspace {
   uint16_t* word_prefix;  // nblk * 16: visible instances of the block before each 64-instance word
 };
 
-__host__ __device__ inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+__host__ __device__ constexpr uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
 __host__ __device__ inline DetWorkspace carve(void* base, uint64_t n, uint32_t m) {
   const uint64_t nblk = (n + kBlockInstances - 1) / kBlockInstances;
@@ -514,12 +516,48 @@ __global__ __launch_bounds__(256) void cull_place_kernel(const CullParams p, uin
   }
 }
 
-}  // namespace
-
-uint64_t vkr_cull_workspace_size(uint64_t n, uint32_t m) {
+constexpr uint64_t workspace_size(uint64_t n, uint32_t m) {
   const uint64_t nblk = (n + kBlockInstances - 1) / kBlockInstances;
   return align_up(nblk * kWordsPerBlock * 8, 256) + 2 * align_up(nblk * 4, 256) + 2 * align_up((nblk + 1) * 4, 256) +
          align_up(((uint64_t)m + 1) * 4, 256) + align_up(nblk * kWordsPerBlock * 2, 256);
+}
+
+}  // namespace
+
+// Workspace of the deterministic mode for callers that must not allocate: one array per GPU, part of the
+// code object, sized for the largest call the allocation-free entry point accepts (every term of
+// workspace_size grows with n and m, so any smaller call fits).  Host code never passes `scratch` itself to
+// a kernel or a memory call - on the host that name is only a handle for hipGetSymbolAddress; the device
+// address it yields differs per GPU and is kept in g_scratch_ptr.
+constexpr uint64_t kScratchBytes = workspace_size(kCullStaticMaxInstances, kCullStaticMaxMeshes);
+static_assert(kScratchBytes <= (1ull << 20), "the static workspace is meant to stay modest");
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+void* g_scratch_ptr[kMaxDevices] = {};
+}  // namespace
+
+uint64_t vkr_cull_workspace_size(uint64_t n, uint32_t m) { return workspace_size(n, m); }
+
+hipError_t vkr_cull_static_init(int device) {
+  if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (g_scratch_ptr[device]) return hipSuccess;
+  void* ptr = nullptr;
+  const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));  // the address on the current device
+  if (e != hipSuccess) return e;
+  if (!ptr || (reinterpret_cast<uintptr_t>(ptr) & 255u)) return hipErrorInvalidSymbol;
+  g_scratch_ptr[device] = ptr;
+  return hipSuccess;
+}
+
+void* vkr_cull_static_workspace(int device, uint64_t* out_bytes) {
+  if (out_bytes) *out_bytes = kScratchBytes;
+  if (device < 0 || device >= kMaxDevices) return nullptr;
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  return g_scratch_ptr[device];
 }
 
 hipError_t vkr_launch_cull_atomic(const CullParams& p, hipStream_t stream) {

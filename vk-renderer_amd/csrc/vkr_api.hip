@@ -205,10 +205,12 @@ int32_t run_deferred(vkr_context* ctx, const vkr_deferred_args* a) {
   return VKR_OK;
 }
 
-int32_t run_cull(vkr_context* ctx, const vkr_cull_args* a) {
+// static_ws != null: the allocation-free entry point; the deterministic kernels run in that workspace.
+int32_t run_cull(vkr_context* ctx, const vkr_cull_args* a, void* static_ws = nullptr, uint64_t static_ws_bytes = 0) {
   if (!ctx || !a) return fail(VKR_ERR_INVALID_ARGUMENT, "vkr_prep_indirect: null argument");
   if (a->instance_count >= (1ull << 31)) return fail(VKR_ERR_INVALID_ARGUMENT, "instance_count %llu >= 2^31", (unsigned long long)a->instance_count);
   if (a->flags & ~VKR_CULL_DETERMINISTIC) return fail(VKR_ERR_INVALID_ARGUMENT, "unknown flags 0x%x", a->flags);
+  static_assert(VKR_NOALLOC_MAX_INSTANCES == kCullStaticMaxInstances && VKR_NOALLOC_MAX_MESHES == kCullStaticMaxMeshes, "header limits = kernel limits");
   if (a->mesh_count == 0u) {
     if (a->instance_count != 0u) return fail(VKR_ERR_INVALID_ARGUMENT, "instances without meshes");
     return VKR_OK;
@@ -233,7 +235,12 @@ int32_t run_cull(vkr_context* ctx, const vkr_cull_args* a) {
   p.first_instance = a->first_instance;
   std::memcpy(p.planes, a->planes, sizeof(p.planes));
   VKR_HIP(hipSetDevice(ctx->device));
-  if (a->flags & VKR_CULL_DETERMINISTIC) {
+  if (static_ws) {
+    if (vkr_cull_workspace_size(a->instance_count, a->mesh_count) > static_ws_bytes)
+      return fail(VKR_ERR_INVALID_ARGUMENT, "static workspace too small for %llu instances, %u meshes", (unsigned long long)a->instance_count, a->mesh_count);
+    p.workspace = static_ws;
+    VKR_HIP(vkr_launch_cull_deterministic(p, ctx->stream));
+  } else if (a->flags & VKR_CULL_DETERMINISTIC) {
     const uint64_t need = vkr_cull_workspace_size(a->instance_count, a->mesh_count);
     if (!a->workspace || a->workspace_bytes < need)
       return fail(VKR_ERR_INVALID_ARGUMENT, "deterministic cull needs a %llu-byte workspace (got %llu)", (unsigned long long)need,
@@ -362,6 +369,9 @@ int32_t vkr_context_create(int32_t device_ordinal, vkr_context** out_ctx) {
   VKR_HIP(hipGetDeviceProperties(&ctx->props, device_ordinal));
   if (std::strncmp(ctx->props.gcnArchName, "gfx950", 6) != 0)
     return fail(VKR_ERR_UNSUPPORTED, "device %d is %s; this library carries gfx950 code only", device_ordinal, ctx->props.gcnArchName);
+  // resolves the per-GPU address of the static cull workspace now, so that vkr_prep_indirect_noalloc never
+  // triggers a first-use code object load (which allocates) on this device
+  VKR_HIP(vkr_cull_static_init(device_ordinal));
   VKR_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   *out_ctx = ctx.release();
   return VKR_OK;
@@ -505,6 +515,20 @@ int32_t vkr_buffer_fill_u32(vkr_buffer* buf, uint64_t offset, uint32_t value, ui
 int32_t vkr_deferred_resolve(vkr_context* ctx, const vkr_deferred_args* args) { return run_deferred(ctx, args); }
 int32_t vkr_prep_indirect(vkr_context* ctx, const vkr_cull_args* args) { return run_cull(ctx, args); }
 uint64_t vkr_cull_workspace_bytes(uint64_t instance_count, uint32_t mesh_count) { return vkr_cull_workspace_size(instance_count, mesh_count); }
+
+int32_t vkr_prep_indirect_noalloc(vkr_context* ctx, const vkr_cull_args* args) {
+  if (!ctx || !args) return fail(VKR_ERR_INVALID_ARGUMENT, "vkr_prep_indirect_noalloc: null argument");
+  if (args->instance_count > VKR_NOALLOC_MAX_INSTANCES)
+    return fail(VKR_ERR_INVALID_ARGUMENT, "vkr_prep_indirect_noalloc: %llu instances exceed the limit of %llu (use vkr_prep_indirect with a workspace)",
+                (unsigned long long)args->instance_count, (unsigned long long)VKR_NOALLOC_MAX_INSTANCES);
+  if (args->mesh_count > VKR_NOALLOC_MAX_MESHES)
+    return fail(VKR_ERR_INVALID_ARGUMENT, "vkr_prep_indirect_noalloc: %u meshes exceed the limit of %u (use vkr_prep_indirect with a workspace)",
+                args->mesh_count, (unsigned)VKR_NOALLOC_MAX_MESHES);
+  uint64_t ws_bytes = 0;
+  void* ws = vkr_cull_static_workspace(ctx->device, &ws_bytes);
+  if (!ws) return fail(VKR_ERR_BAD_STATE, "vkr_prep_indirect_noalloc: static workspace of device %d was not resolved at context creation", ctx->device);
+  return run_cull(ctx, args, ws, ws_bytes);
+}
 
 int32_t vkr_kernel_get(vkr_context* ctx, const char* name, vkr_kernel** out_kernel) {
   if (!ctx || !name || !out_kernel) return fail(VKR_ERR_INVALID_ARGUMENT, "vkr_kernel_get: null argument");

@@ -65,5 +65,13 @@ struct CullParams {
 };
 
 uint64_t vkr_cull_workspace_size(uint64_t instance_count, uint32_t mesh_count);
+// The deterministic mode's workspace as a per-GPU array inside the code object, for the entry point that
+// allocates nothing.  vkr_cull_static_init(device) resolves the array's address on `device`, which must be
+// the current device (once per device, at context creation: the first use of a code object on a device
+// may allocate); vkr_cull_static_workspace returns that address (null before init) and the array's size.
+constexpr uint64_t kCullStaticMaxInstances = 1ull << 22;
+constexpr uint32_t kCullStaticMaxMeshes = 1u << 16;
+hipError_t vkr_cull_static_init(int device);
+void* vkr_cull_static_workspace(int device, uint64_t* out_bytes);
 hipError_t vkr_launch_cull_atomic(const CullParams& p, hipStream_t stream);
 hipError_t vkr_launch_cull_deterministic(const CullParams& p, hipStream_t stream);
