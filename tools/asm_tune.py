@@ -197,6 +197,34 @@ def retune(asm_text: str, seed: int = 1) -> tuple[str, list[dict]]:
     return "\n".join(lines), reports
 
 
+def compile_with_pass(hipcc: str, src: str, obj: str, flags: list[str], verbose: bool = False) -> list[dict]:
+    """hipcc's own steps, split so that the device assembly can be edited: device code to assembly, retune(),
+    assemble + link to a code object, bundle it, compile the host side with that bundle embedded.  The result is
+    an ordinary HIP object file that can replace lib/deferred.o before the link step of vk-renderer_amd/build.py.
+    An experiment only: the renumbered kernel measured within 1 % of the plain build."""
+    import os
+    import subprocess
+    import sys
+    llvm_bin = os.environ.get("ROCM_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+    stem = obj[:-2]
+    dev_s, tuned_s, dev_o, dev_co, fatbin = stem + ".gfx950.s", stem + ".gfx950.tuned.s", stem + ".gfx950.o", stem + ".gfx950.co", stem + ".hipfb"
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+
+    run([hipcc, "--cuda-device-only", "-S", src, "-o", dev_s] + flags)
+    text, reports = retune(open(dev_s).read())
+    open(tuned_s, "w").write(text)
+    run([os.path.join(llvm_bin, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", tuned_s, "-o", dev_o])
+    run([os.path.join(llvm_bin, "lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o", dev_co, dev_o])
+    run([os.path.join(llvm_bin, "clang-offload-bundler"), "-type=o", "-bundle-align=4096",
+         "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950", "-input=/dev/null", f"-input={dev_co}", f"-output={fatbin}"])
+    run([hipcc, "--cuda-host-only", "-c", src, "-o", obj] + flags + ["-Xclang", "-fcuda-include-gpubinary", "-Xclang", fatbin])
+    return reports
+
+
 if __name__ == "__main__":
     import sys
     text, reps = retune(open(sys.argv[1]).read())
