@@ -112,9 +112,12 @@ typedef struct vkr_image2d {
 #define VKR_DEFERRED_RADIUS_CUTOFF 1u /* extension: a light contributes only where dist^2 < pointLightRadius^2
                                          (push[3]); enables per-tile light lists.  Off = reference behaviour
                                          (pointLightRadius is pushed but never read, deferred.comp:8,120-129).
-                                         From 256 lights up the call first lists the lights per 128 x 128 pixel bin
-                                         in context-owned device memory (4 bytes per bin and light; allocated or
-                                         grown inside the call, released with the context; skipped above 256 MiB). */
+                                         The call lists the lights that can reach each 32 x 32 pixel tile (up to 65536
+                                         lights; from 256 lights up via a coarse level of 128 x 128 pixel bins), writes
+                                         the tiles no light reaches straight away (their pixels are their ambient term)
+                                         and shades the others from their lists.  Lists, bins and the queue of lit tiles
+                                         live in context-owned device memory (1 KiB + 8 bytes per tile, 4 bytes per bin
+                                         and light; allocated or grown inside the call, released with the context). */
 #define VKR_DEFERRED_NO_TILE_LISTS 2u /* with RADIUS_CUTOFF: apply the cutoff per pixel only and loop over the whole
                                          light table (diagnostic; results are bit-identical to the tiled path) */
 
@@ -141,6 +144,21 @@ typedef struct vkr_deferred_args {
 } vkr_deferred_args;
 
 VKR_API int32_t vkr_deferred_resolve(vkr_context* ctx, const vkr_deferred_args* args);
+
+/* Measurement support, no counterpart in the reference: what the light lists of the context's most recent
+ * resolve with VKR_DEFERRED_RADIUS_CUTOFF looked like.  light_pixels / pixels is the mean number of lights a
+ * pixel's loop walked (the L that the work of the frame is proportional to).  Waits for the context's stream. */
+typedef struct vkr_tile_stats {
+  uint32_t tiles;          /* 32 x 32 pixel tiles of the frame */
+  uint32_t dark_tiles;     /* no light reaches them: written as ambient colour by the listing launch */
+  uint32_t listed_tiles;   /* shaded from their own list */
+  uint32_t overflow_tiles; /* more reaching lights than a list holds: shaded from their bin's candidates / the table */
+  uint32_t max_list;       /* longest list among the listed tiles */
+  uint32_t list_cap;       /* entries a list holds */
+  uint64_t light_pixels;   /* sum over tiles of lights walked x pixels of the tile inside the image */
+  uint64_t pixels;         /* width x height */
+} vkr_tile_stats;
+VKR_API int32_t vkr_deferred_tile_stats(vkr_context* ctx, vkr_tile_stats* out);
 
 /* VkDrawIndexedIndirectCommand, 20 bytes, one per mesh
  * (/root/reference/src/vkmodel.cpp:79,96; consumed at /root/reference/inc/vkmodel.hpp:72). */

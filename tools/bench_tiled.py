@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Times the radius-cutoff extension with per-tile LDS light lists against the same cutoff applied per
+"""Times the radius-cutoff extension with per-tile light lists against the same cutoff applied per
 pixel over the whole table (BASELINE config: 7680x4320, 4096 lights; one GPU does the whole frame here).
 
     python tools/bench_tiled.py [--width W --height H --lights L --radius R --steps K]
@@ -61,6 +61,8 @@ def main():
         ctx.wait_idle()
         ms = e1.elapsed_ms_since(e0) / a.steps
         res[name] = {"ms": ms, "Gpixel_per_s": a.width * a.height / ms / 1e6, "hbm_GBps": a.width * a.height * 24 / ms / 1e6}
+        if name == "tiled":
+            res[name]["lists"] = ctx.tile_stats()
         outs[name] = out.download(np.uint8, 4)
     if len(outs) == 2:
         res["identical"] = bool(np.array_equal(outs["tiled"], outs["per_pixel_cutoff_whole_table"]))

@@ -58,6 +58,11 @@ class DeferredArgs(C.Structure):
                 ("row_offset", C.c_uint32), ("full_height", C.c_uint32), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class TileStats(C.Structure):
+    _fields_ = [("tiles", C.c_uint32), ("dark_tiles", C.c_uint32), ("listed_tiles", C.c_uint32), ("overflow_tiles", C.c_uint32),
+                ("max_list", C.c_uint32), ("list_cap", C.c_uint32), ("light_pixels", C.c_uint64), ("pixels", C.c_uint64)]
+
+
 class CullArgs(C.Structure):
     _fields_ = [("aabb_min", C.c_void_p), ("aabb_max", C.c_void_p), ("instance_count", C.c_uint64),
                 ("planes", C.c_float * 24), ("mesh_base", C.c_void_p), ("mesh_count", C.c_uint32),
@@ -142,6 +147,7 @@ EXPORTS = {
     "vkr_buffer_download": (C.c_int32, [_P, C.c_uint64, _P, C.c_uint64]),
     "vkr_buffer_fill_u32": (C.c_int32, [_P, C.c_uint64, C.c_uint32, C.c_uint64]),
     "vkr_deferred_resolve": (C.c_int32, [_P, C.POINTER(DeferredArgs)]),
+    "vkr_deferred_tile_stats": (C.c_int32, [_P, C.POINTER(TileStats)]),
     "vkr_prep_indirect": (C.c_int32, [_P, C.POINTER(CullArgs)]),
     "vkr_cull_workspace_bytes": (C.c_uint64, [C.c_uint64, C.c_uint32]),
     "vkr_prep_indirect_noalloc": (C.c_int32, [_P, C.POINTER(CullArgs)]),
@@ -428,6 +434,14 @@ class Context:
     # --- typed entry points -----------------------------------------------------------------
     def deferred_resolve(self, args: DeferredArgs):
         _check(lib().vkr_deferred_resolve(self.handle, C.byref(args)))
+
+    def tile_stats(self) -> dict:
+        """Light-list statistics of the most recent radius-cutoff resolve (waits for the stream)."""
+        st = TileStats()
+        _check(lib().vkr_deferred_tile_stats(self.handle, C.byref(st)))
+        d = {name: int(getattr(st, name)) for name, _ in TileStats._fields_}
+        d["mean_lights_per_pixel"] = d["light_pixels"] / max(d["pixels"], 1)
+        return d
 
     def prep_indirect(self, args: CullArgs):
         _check(lib().vkr_prep_indirect(self.handle, C.byref(args)))

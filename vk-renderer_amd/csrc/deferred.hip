@@ -44,10 +44,6 @@
 
 #include "vkr_kernels.h"
 
-#ifndef VKR_TILE_BATCH_FIRST
-#define VKR_TILE_BATCH_FIRST 8u
-#endif
-
 namespace {
 
 constexpr float kPi = 3.14159f;  // deferred.comp:3 (truncated on purpose)
@@ -59,7 +55,6 @@ constexpr float kInvDistFloor = 1e7f;      // 1 / kDistFloor
 constexpr float kStepScale = 0x1p100f;     // (c - 1e-6) * 2^100 saturates the clamp for any c > 1e-6
 constexpr float kRadiusStepScale = 0x1p80f;
 constexpr int kChunk = 512;                // lights per LDS chunk: 2 float4 each = 16 KiB
-constexpr int kTileSpan = 4096;            // tile light lists: lights tested per pass (64 groups of 64)
 
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -307,30 +302,127 @@ __device__ __forceinline__ uint32_t quantize_unorm8(float c) {
   return (uint32_t)__builtin_rintf(t * 255.0f);
 }
 
+// Shading cost class of a tile by the length of its list; the shading launch takes the classes from the top down.
+__device__ __forceinline__ uint32_t list_class(uint32_t count) { return count < 8u ? 0u : count < 32u ? 1u : count < 128u ? 2u : 3u; }
+static_assert(kListClasses == 4, "list_class() has four classes");
+
+__device__ __forceinline__ uint4 load_stream_u4(const uint8_t* ptr) {
+  typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+  const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(ptr));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// Four consecutive pixels of an output row, `valid` of them inside the image.
+__device__ __forceinline__ void store_rgba8x4(uint8_t* orow, uint32_t x0, uint32_t valid, const uint32_t (&packed)[4]) {
+  uint32_t* o = reinterpret_cast<uint32_t*>(orow) + x0;
+  if (valid == 4u) {
+    *reinterpret_cast<uint4*>(o) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if ((uint32_t)i < valid) o[i] = packed[i];
+  }
+}
+
+template <int kOutMode>
+__device__ __forceinline__ void store_float4x4(uint8_t* orow, uint32_t x0, uint32_t valid, const float (&rgb)[4][3]) {
+  if (kOutMode == kOutRgba16f) {
+    uint2* o = reinterpret_cast<uint2*>(orow) + x0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if ((uint32_t)i < valid) {
+        const __half2 a = __floats2half2_rn(rgb[i][0], rgb[i][1]);
+        const __half2 b = __floats2half2_rn(rgb[i][2], 1.0f);
+        o[i] = make_uint2(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b));
+      }
+    }
+  } else {
+    float4* o = reinterpret_cast<float4*>(orow) + x0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if ((uint32_t)i < valid) o[i] = make_float4(rgb[i][0], rgb[i][1], rgb[i][2], 1.0f);
+  }
+}
+
 // Work decomposition: a 256-thread workgroup shades a 32 x 32 pixel tile; lane t owns the four
 // consecutive pixels (4*(t&7) .. +3, t>>3) of the tile, so every G-buffer plane is read with one
 // 128-bit load per lane (two for the 8-byte normals) and the 8-bit result is written with one.
 // The lane shades its four pixels as two pairs; each pair runs the light loop two lights at a time.
 // The light records (pos.xyz, color.xyz as two float4) go through LDS in lists of up to kChunk,
 // padded to an even count with a black light:
-//   kTile = false : the whole table, chunk after chunk;
-//   kTile = true  : (radius cutoff only) the lights whose sphere of influence reaches the tile's
-//                   world-space bounding box, in table order.
+//   kList = false : one workgroup per tile of the launch grid; the whole table, chunk after chunk;
+//   kList = true  : (radius cutoff only) the workgroups of a fixed-size grid take the lit tiles that
+//                   tile_lists_kernel queued, q = blockIdx.x, blockIdx.x + gridDim.x, ..., and gather the
+//                   records named by the tile's index list (table order).  A tile whose list overflowed its
+//                   capacity walks its coarse bin's candidates (or the whole table) instead; the per-pixel
+//                   cutoff makes any superset of the reaching lights give the same bits.
 // launch bound: 4 waves per SIMD (<= 128 VGPRs); measured 1-2 % faster than the 3 waves the allocator
-// settles on unprompted.  The tile-list variants get 3 waves (<= 168 VGPRs): at 128 they spill some 30
-// registers, and a kernel that uses scratch memory at all measured 0.14 ms slower per 8K frame.
-template <int kOutMode, bool kRadius, bool kTile>
-__global__ __launch_bounds__(256, kTile ? 3 : 4) void deferred_kernel(const DeferredParams p) {
+// settles on unprompted.  The list variant gets 3 waves (<= 168 VGPRs): at 128 it spills 13-23 registers.
+template <int kOutMode, bool kRadius, bool kList>
+__global__ __launch_bounds__(256, kList ? 3 : 4) void deferred_kernel(const DeferredParams p) {
   __shared__ float4 s_light[2 * kChunk + 4];  // +1 pair: the prefetch of the last iteration reads past the list
   __shared__ uint32_t s_stash[14][256];  // rows: see kRow* below
-  __shared__ float s_red[8];
   const uint32_t t = threadIdx.x;
-  const uint32_t x0 = blockIdx.x * 32u + (t & 7u) * 4u;
-  const uint32_t y = blockIdx.y * 32u + (t >> 3);
+  const float4* __restrict__ lights = reinterpret_cast<const float4*>(p.lights);
+  const uint32_t L = p.light_count;
+  LoopConsts kc;
+  // loop constants pinned in VGPRs: as SGPR or literal operands they would halve the issue rate of their users
+  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.step_scale) : "s"(kStepScale));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.step_bias) : "s"(-kEarlyOut * kStepScale));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.dist_floor) : "s"(kDistFloor));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.radius2_scaled) : "s"(p.radius2 * kRadiusStepScale));
+
+  // kList: tiles come from four queues, heaviest list class first (long tiles started last would leave most of the
+  // chip idle behind them), handed out through a ticket counter so that workgroups take tiles at the rate they
+  // finish them.  The queue lengths are fixed before the launch and every ticket beyond their sum ends its
+  // workgroup, so the grid drains.
+  __shared__ uint32_t s_ticket;
+  uint32_t class_end[kListClasses] = {};
+  if (kList) {
+    uint32_t run = 0;
+#pragma unroll
+    for (int c = kListClasses - 1; c >= 0; --c) {
+      run += p.lit_counters[c];
+      class_end[kListClasses - 1 - c] = run;
+    }
+    if (t == 0u) s_ticket = atomicAdd(const_cast<uint32_t*>(p.lit_counters) + kListClasses, 1u);
+    __syncthreads();
+  }
+  const uint32_t q_end = kList ? class_end[kListClasses - 1] : 1u;
+  uint32_t q = kList ? s_ticket : 0u;
+#pragma unroll 1
+  while (q < q_end) {
+  uint32_t tile_x = blockIdx.x, tile_y = blockIdx.y;
+  uint32_t count = L;                       // lights this tile walks
+  const uint16_t* __restrict__ tl = nullptr;    // kList: the tile's own list, or
+  const uint32_t* __restrict__ cand = nullptr;  //        its bin's candidates when the list overflowed
+  uint32_t next_ticket = 0;
+  if (kList) {
+    uint32_t cls = kListClasses - 1u, first = 0u;  // position q of the concatenated queues -> (class, index)
+#pragma unroll
+    for (uint32_t k = 0; k + 1u < kListClasses; ++k)
+      if (q >= class_end[k]) cls = kListClasses - 2u - k, first = class_end[k];
+    const uint32_t tile = p.lit_queue[(size_t)cls * (p.tiles_x * p.tiles_y) + (q - first)];
+    tile_y = tile / p.tiles_x;
+    tile_x = tile - tile_y * p.tiles_x;
+    const uint32_t word = p.tile_count[tile];
+    if (word & kTileOverflow) {
+      if (p.bin_list) {
+        const uint32_t bin_index = (tile_y * 32u / kBinPixels) * p.bins_x + tile_x * 32u / kBinPixels;
+        cand = p.bin_list + (size_t)bin_index * L;
+        count = p.bin_count[bin_index];
+      }
+    } else {
+      tl = p.tile_list + (size_t)tile * p.list_cap;
+      count = word;
+    }
+  }
+  const uint32_t x0 = tile_x * 32u + (t & 7u) * 4u;
+  const uint32_t y = tile_y * 32u + (t >> 3);
   const bool inside = (x0 < p.width) && (y < p.height);
   // lanes outside the image shade the tile's first group (in bounds by construction) and store nothing
-  const uint32_t lx = inside ? x0 : blockIdx.x * 32u;
-  const uint32_t ly = inside ? y : blockIdx.y * 32u;
+  const uint32_t lx = inside ? x0 : tile_x * 32u;
+  const uint32_t ly = inside ? y : tile_y * 32u;
   const uint32_t y_full = ly + p.row_offset;
 
   const uint4 alb4 = *reinterpret_cast<const uint4*>(p.albedo + (size_t)ly * p.pitch_albedo + (size_t)lx * 4u);
@@ -366,177 +458,12 @@ __global__ __launch_bounds__(256, kTile ? 3 : 4) void deferred_kernel(const Defe
   s_stash[kRowNormal + 1][t] = nrmB.y;
   s_stash[kRowNormal + 2][t] = nrmB.z;
   s_stash[kRowNormal + 3][t] = nrmB.w;
-  float dmin_lane = fminf(fminf(dep4.x, dep4.y), fminf(dep4.z, dep4.w));
-  float dmax_lane = fmaxf(fmaxf(dep4.x, dep4.y), fmaxf(dep4.z, dep4.w));
 
-  const float4* __restrict__ lights = reinterpret_cast<const float4*>(p.lights);
-  const uint32_t L = p.light_count;
-  LoopConsts kc;
-  // loop constants pinned in VGPRs: as SGPR or literal operands they would halve the issue rate of their users
-  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.step_scale) : "s"(kStepScale));
-  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.step_bias) : "s"(-kEarlyOut * kStepScale));
-  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.dist_floor) : "s"(kDistFloor));
-  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.radius2_scaled) : "s"(p.radius2 * kRadiusStepScale));
   const bool wave_live = __ballot(inside) != 0ull;  // wave-uniform
-  const uint32_t lane = t & 63u, wv = t >> 6;
-
-  // ---- tile bounds (kTile): world-space box around every pixel position of the tile ----------------
-  // s_tile: box_lo[3], box_hi[3], four side faces of the tile's pyramid (outward unit normal + offset),
-  // reach = radius + reconstruction pad.  Block-uniform, so it lives in LDS (broadcast reads) rather
-  // than in 23 VGPRs of every lane.
-  __shared__ float s_tile[23];
-  __shared__ uint64_t s_group_hits[kTileSpan / 64];        // kTile: ballot word of each 64-light group of the span
-  __shared__ uint32_t s_group_before[kTileSpan / 64 + 1];  // kTile: listed lights before each group
-  if (kTile) {
-    float dmin = dmin_lane, dmax = dmax_lane;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      dmin = fminf(dmin, __shfl_xor(dmin, off));
-      dmax = fmaxf(dmax, __shfl_xor(dmax, off));
-    }
-    if (lane == 0u) {
-      s_red[wv] = dmin;
-      s_red[4u + wv] = dmax;
-    }
-    __syncthreads();
-    if (wv == 0u) {  // block-uniform values: one wave computes them, the others wait at the barrier below
-      dmin = fminf(fminf(s_red[0], s_red[1]), fminf(s_red[2], s_red[3]));
-      dmax = fmaxf(fmaxf(s_red[4], s_red[5]), fmaxf(s_red[6], s_red[7]));
-      // The pixel positions are the images of points of the clip-space box [xa,xb] x [ya,yb] x [dmin,dmax]
-      // under the projective map inverseVP; with w > 0 on all eight corners their hull contains them all.
-      const float xa = (float)(blockIdx.x * 32u) / (float)p.width * 2.0f - 1.0f;
-      const float xb = (float)min(blockIdx.x * 32u + 32u, p.width) / (float)p.width * 2.0f - 1.0f;
-      const float ya = (float)(blockIdx.y * 32u + p.row_offset) / (float)p.full_height * 2.0f - 1.0f;
-      const float yb = (float)(min(blockIdx.y * 32u + 32u, p.height) + p.row_offset) / (float)p.full_height * 2.0f - 1.0f;
-      // Twelve points, one per lane: lane 4*kind + c holds corner c (xa ya, xb ya, xb yb, xa yb) at depth dmin
-      // (kind 0, the near points), dmax (kind 1, the far points) or dmin - 0.25 (kind 2, a second point of the
-      // same pixel ray).  Lanes from 12 up repeat them.
-      const uint32_t c = lane & 3u, kind = (lane >> 2) % 3u;
-      const float pcx = (c == 1u || c == 2u) ? xb : xa;
-      const float pcy = (c >= 2u) ? yb : ya;
-      const float pcz = kind == 0u ? dmin : (kind == 1u ? dmax : dmin - 0.25f);
-      const float* M = p.inv_vp;
-      const float wx = ((M[0] * pcx + M[4] * pcy) + M[8] * pcz) + M[12];
-      const float wy = ((M[1] * pcx + M[5] * pcy) + M[9] * pcz) + M[13];
-      const float wz = ((M[2] * pcx + M[6] * pcy) + M[10] * pcz) + M[14];
-      const float ww = ((M[3] * pcx + M[7] * pcy) + M[11] * pcz) + M[15];
-      const float q[3] = {wx / ww, wy / ww, wz / ww};
-      const bool ok = (ww > 1e-30f) && (fabsf(q[0]) < 1e30f) && (fabsf(q[1]) < 1e30f) && (fabsf(q[2]) < 1e30f);
-      const bool sane = (__ballot(ok) & 0xFFFull) == 0xFFFull;
-      // box over the near and far points: lanes 0..7, which the xor offsets 1, 2, 4 keep among themselves
-      float box_lo[3], box_hi[3];
-      float scale = 0.0f;
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        box_lo[a] = q[a];
-        box_hi[a] = q[a];
-#pragma unroll
-        for (int off = 1; off <= 4; off <<= 1) {
-          box_lo[a] = fminf(box_lo[a], __shfl_xor(box_lo[a], off));
-          box_hi[a] = fmaxf(box_hi[a], __shfl_xor(box_hi[a], off));
-        }
-        scale = fmaxf(scale, fmaxf(fabsf(box_lo[a]), fabsf(box_hi[a])));
-      }
-      // binary32 reconstruction error of a position is ~2e-4 relative at the far end of the depth range
-      const float pad = 2e-3f * scale + 1e-2f;
-      // the four side faces of the tile's pyramid, face c in lane c: plane through rays c and c+1, normal pointing
-      // away from ray c+2
-      float near1[3], near2[3], ray[3];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        near1[a] = __shfl(q[a], (int)((lane + 1u) & 3u));
-        near2[a] = __shfl(q[a], (int)((lane + 2u) & 3u));
-        ray[a] = __shfl(q[a], (int)(8u + c));
-      }
-      const float ux = ray[0] - q[0], uy = ray[1] - q[1], uz = ray[2] - q[2];
-      const float vx = near1[0] - q[0], vy = near1[1] - q[1], vz = near1[2] - q[2];
-      float nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
-      const float len2 = nx * nx + ny * ny + nz * nz;
-      const float inv = len2 > 0.0f ? rsq_(len2) : 0.0f;  // degenerate face: zero normal, never culls
-      nx *= inv; ny *= inv; nz *= inv;
-      const float side = nx * (near2[0] - q[0]) + ny * (near2[1] - q[1]) + nz * (near2[2] - q[2]);
-      const float flip = side > 0.0f ? -1.0f : 1.0f;
-      const float fx = sane ? flip * nx : 0.0f, fy = sane ? flip * ny : 0.0f, fz = sane ? flip * nz : 0.0f;
-      if (lane < 4u) {
-        s_tile[6u + 4u * lane + 0u] = fx;
-        s_tile[6u + 4u * lane + 1u] = fy;
-        s_tile[6u + 4u * lane + 2u] = fz;
-        // signed distance of x to the face = dot(n, x) - dot(n, near point c)
-        s_tile[6u + 4u * lane + 3u] = -(fx * q[0] + fy * q[1] + fz * q[2]);
-      }
-      if (lane == 0u) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          s_tile[a] = sane ? box_lo[a] - pad : -INFINITY;
-          s_tile[3 + a] = sane ? box_hi[a] + pad : INFINITY;
-        }
-        s_tile[22] = sqrt_(p.radius2) + pad;  // reach
-      }
-    }
-    __syncthreads();
-  }
-
-  // kTile: the candidates of this tile are the lights of its coarse bin when the launch carries bins, else
-  // the whole table; positions below index that candidate list.
-  const uint32_t bin_index = (blockIdx.y * 32u / kBinPixels) * p.bins_x + blockIdx.x * 32u / kBinPixels;
-  const uint32_t* __restrict__ bin = (kTile && p.bin_list) ? p.bin_list + (size_t)bin_index * L : nullptr;
-  const uint32_t LL = bin ? p.bin_count[bin_index] : L;
-
-  // kTile, pass 1 over the candidates [span, span + kTileSpan): every wave tests its share of the span's 64-light
-  // groups against the tile bounds and leaves one ballot word per group in LDS - no barrier between groups -
-  // then one wave turns the popcounts into list offsets.
-  auto test_span = [&](uint32_t span, auto batch) {
-    constexpr uint32_t kBatch = decltype(batch)::value;  // groups a wave tests per trip: that many position loads in flight
-    const uint32_t span_lights = min((uint32_t)kTileSpan, LL - span);
-    const uint32_t groups = (span_lights + 63u) >> 6;
-    const float reach = s_tile[22];
-    for (uint32_t grp0 = wv; grp0 < groups; grp0 += 4u * kBatch) {
-      float4 lp[kBatch];
-#pragma unroll
-      for (uint32_t u = 0; u < kBatch; ++u) {
-        const uint32_t pos = min(span + (grp0 + 4u * u) * 64u + lane, LL - 1u);
-        lp[u] = lights[3u * (bin ? bin[pos] : pos)];
-      }
-#pragma unroll
-      for (uint32_t u = 0; u < kBatch; ++u) {
-        const uint32_t grp = grp0 + 4u * u;
-        const uint32_t pos = span + grp * 64u + lane;
-        const float dx = fmaxf(fmaxf(s_tile[0] - lp[u].x, lp[u].x - s_tile[3]), 0.0f);
-        const float dy = fmaxf(fmaxf(s_tile[1] - lp[u].y, lp[u].y - s_tile[4]), 0.0f);
-        const float dz = fmaxf(fmaxf(s_tile[2] - lp[u].z, lp[u].z - s_tile[5]), 0.0f);
-        bool hit = (pos < LL) & ((dx * dx + dy * dy + dz * dz) < p.radius2);  // NaN position: never contributes, never listed
-        if (__ballot(hit) != 0ull) {  // the box rejects most lights of most groups: one uniform branch skips the face tests
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {  // outside a side face by more than the radius: cannot reach any pixel of the tile
-            const float* f = &s_tile[6 + 4 * c];
-            hit &= !(((f[0] * lp[u].x + f[1] * lp[u].y) + f[2] * lp[u].z) + f[3] > reach);  // no short circuit: straight-line code
-          }
-        }
-        const uint64_t hits = __ballot(hit);
-        if (lane == 0u && grp < groups) s_group_hits[grp] = hits;
-      }
-    }
-    __syncthreads();
-    if (wv == 0u) {
-      const uint32_t mine = lane < groups ? (uint32_t)__popcll(s_group_hits[lane]) : 0u;
-      uint32_t incl = mine;
-#pragma unroll
-      for (uint32_t d = 1; d < 64u; d <<= 1) {
-        const uint32_t o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
-      }
-      s_group_before[lane + 1u] = incl;
-      if (lane == 0u) s_group_before[0] = 0u;
-    }
-    __syncthreads();
-  };
-  // The first span is tested before any per-pixel state exists (fewer live registers); with at most
-  // kTileSpan lights that is the only pass 1 of the workgroup, and both pixel pairs use its words.
-  if (kTile && LL > 0u) test_span(0u, std::integral_constant<uint32_t, VKR_TILE_BATCH_FIRST>());
-
-  bool list_complete = false;  // kTile: the list built for the first pixel pair holds every reaching light
-  uint32_t list_count = 0;
   float last[2][3] = {};  // float outputs: the second pair's colours
+  // The next ticket is requested here, after the loads of this tile have been waited for (a returning atomic
+  // ahead of them would hold their data back: returns come in order), and read at the end of the tile.
+  if (kList && t == 0u) next_ticket = atomicAdd(const_cast<uint32_t*>(p.lit_counters) + kListClasses, 1u);
 
   // results: the first pair's go to LDS (over the rows of the words just consumed) until the second
   // pair is done, so that each lane writes its four pixels with full-width stores
@@ -553,25 +480,9 @@ __global__ __launch_bounds__(256, kTile ? 3 : 4) void deferred_kernel(const Defe
     }
   };
 
-  // kTile: no light reaches this tile (block-uniform; known after the only pass 1 when the candidates fit one
-  // span).  Every light sum of deferred.comp:120-129 is then zero and the pixel is its ambient term
-  // (deferred.comp:107), whatever its position and normal are: nothing of the per-pixel setup is needed.
-  // (Only the tile-list variants take this path: as a run-time test in the other variants, for a table of
-  // zero lights, it costs them four spilled registers.)
-  const bool tile_dark = kTile && LL <= (uint32_t)kTileSpan && (LL == 0u || s_group_before[(LL + 63u) >> 6] == 0u);
-
   // One copy of the light loop serves both pixel pairs (no unrolling): half the code, same speed.
 #pragma unroll 1
   for (int g = 0; g < 4; g += 2) {
-    if (tile_dark) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const uint32_t albedo = s_stash[kRowAlbedo + g + i][t];
-        const float rgb[3] = {kAmbient * unorm8(albedo, 0), kAmbient * unorm8(albedo, 1), kAmbient * unorm8(albedo, 2)};
-        keep_result(g, i, rgb);
-      }
-      continue;
-    }
     Pixel s[2];
     if (g != 0) {
       mat[0] = s_stash[kRowMaterial + 2][t];
@@ -588,11 +499,11 @@ __global__ __launch_bounds__(256, kTile ? 3 : 4) void deferred_kernel(const Defe
 #pragma unroll
     for (int i = 0; i < 2; ++i) setup_pixel(s[i], p, cx[i], cy, dep[i], mat[i], nlo[i], nhi[i]);
 
-    // shades the first `count` records of s_light (count even, > 0)
-    auto shade_list = [&](uint32_t count) {
+    // shades the first `n` records of s_light (n even, > 0)
+    auto shade_list = [&](uint32_t n) {
       const float4* rec = s_light;
       float4 pa = rec[0], ca = rec[1], pb = rec[2], cb = rec[3];
-      for (uint32_t j = 0; j < count; j += 2u) {
+      for (uint32_t j = 0; j < n; j += 2u) {
         const Light A{pa.x, pa.y, pa.z, ca.x, ca.y, ca.z};
         const Light B{pb.x, pb.y, pb.z, cb.x, cb.y, cb.z};
         rec += 4;  // next pair (one pair beyond the list on the last trip: read, never used)
@@ -605,71 +516,26 @@ __global__ __launch_bounds__(256, kTile ? 3 : 4) void deferred_kernel(const Defe
     };
     const float4 black_pos = make_float4(0.0f, 0.0f, 1e18f, 0.0f), black_col = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 
-    if (!kTile) {
-      for (uint32_t base = 0; base < L; base += kChunk) {
-        const uint32_t n = min((uint32_t)kChunk, L - base);
-        const uint32_t n2 = (n + 1u) & ~1u;
-        __syncthreads();  // previous chunk fully consumed
+    for (uint32_t base = 0; base < count; base += kChunk) {
+      const uint32_t n = min((uint32_t)kChunk, count - base);
+      const uint32_t n2 = (n + 1u) & ~1u;
+      // kList: a list that fits one chunk is still in LDS when the second pixel pair comes round
+      if (!kList || g == 0 || count > (uint32_t)kChunk) {
+        __syncthreads();  // previous chunk (or previous tile's list) fully consumed
         for (uint32_t i = t; i < n2; i += 256u) {
           float4 lp = black_pos, lc = black_col;
           if (i < n) {
-            lp = lights[3u * (base + i)];       // pos.xyz, opening_angle (unused)
-            lc = lights[3u * (base + i) + 1u];  // color.xyz, penumbra_angle (unused)
+            uint32_t idx = base + i;
+            if (kList) idx = tl ? (uint32_t)tl[idx] : (cand ? cand[idx] : idx);
+            lp = lights[3u * idx];       // pos.xyz, opening_angle (unused)
+            lc = lights[3u * idx + 1u];  // color.xyz, penumbra_angle (unused)
           }
           s_light[2u * i] = lp;
           s_light[2u * i + 1u] = lc;
         }
         __syncthreads();
-        if (wave_live) shade_list(n2);
       }
-    } else if (g != 0 && list_complete) {
-      // the first pixel pair listed every reaching light without overflowing: the list is still in LDS
-      if (wave_live && list_count > 0u) shade_list((list_count + 1u) & ~1u);
-    } else {
-      // Lights go through in spans of kTileSpan: pass 1 (test_span) leaves a ballot word and a list offset
-      // per 64-light group; in pass 2 the hit lanes copy their records to the offsets, which keeps table
-      // order (the float sums are order-sensitive).  A span with more hits than the list holds is shaded
-      // in several rounds of whole groups.
-      bool single_round = true;
-      for (uint32_t span = 0; span < LL; span += kTileSpan) {
-        const uint32_t span_lights = min((uint32_t)kTileSpan, LL - span);
-        const uint32_t groups = (span_lights + 63u) >> 6;
-        if (span != 0u || (g != 0 && LL > (uint32_t)kTileSpan)) test_span(span, std::integral_constant<uint32_t, 4u>());
-        const uint32_t total = s_group_before[groups];
-        uint32_t first = 0;  // first group of the round (block-uniform, like everything steering the barriers below)
-        while (first < groups) {
-          const uint32_t before = s_group_before[first];
-          uint32_t end = groups;
-          if (total - before > (uint32_t)kChunk) {
-            end = first + 1u;  // one group always fits
-            while (s_group_before[end + 1u] - before <= (uint32_t)kChunk) ++end;
-            single_round = false;
-          }
-          const uint32_t count = s_group_before[end] - before;
-          if (count > 0u) {
-            for (uint32_t grp = first + wv; grp < end; grp += 4u) {
-              const uint64_t hits = s_group_hits[grp];
-              if ((hits >> lane) & 1ull) {
-                const uint32_t pos = span + grp * 64u + lane;
-                const uint32_t i = bin ? bin[pos] : pos;
-                const uint32_t slot = s_group_before[grp] - before + __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u));
-                s_light[2u * slot] = lights[3u * i];
-                s_light[2u * slot + 1u] = lights[3u * i + 1u];
-              }
-            }
-            if (t == 0u && (count & 1u)) {
-              s_light[2u * count] = black_pos;
-              s_light[2u * count + 1u] = black_col;
-            }
-            __syncthreads();
-            if (wave_live) shade_list((count + 1u) & ~1u);
-            __syncthreads();  // everyone is done reading before the list is rebuilt (or reused)
-          }
-          first = end;
-        }
-        list_count = total;
-      }
-      list_complete = single_round && LL <= (uint32_t)kTileSpan;
+      if (wave_live) shade_list(n2);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -678,47 +544,249 @@ __global__ __launch_bounds__(256, kTile ? 3 : 4) void deferred_kernel(const Defe
       keep_result(g, i, rgb);
     }
   }
-  if (!inside) return;
-
-  const uint32_t valid = min(4u, p.width - x0);
-  uint8_t* orow = p.out + (size_t)y * p.pitch_out;
-  if (kOutMode == kOutRgba8) {
-    uint32_t packed[4];
+  if (inside) {
+    const uint32_t valid = min(4u, p.width - x0);
+    uint8_t* orow = p.out + (size_t)y * p.pitch_out;
+    if (kOutMode == kOutRgba8) {
+      uint32_t packed[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) packed[i] = s_stash[kRowAlbedo + i][t];
-    uint32_t* o = reinterpret_cast<uint32_t*>(orow) + x0;
-    if (valid == 4u) {
-      *reinterpret_cast<uint4*>(o) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+      for (int i = 0; i < 4; ++i) packed[i] = s_stash[kRowAlbedo + i][t];
+      store_rgba8x4(orow, x0, valid, packed);
+    } else {
+      float rgb[4][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int row = k == 0 ? kRowAlbedo : k == 1 ? kRowMaterial : kRowExtra;
+          rgb[i][k] = __uint_as_float(s_stash[row + i][t]);
+          rgb[2 + i][k] = last[i][k];
+        }
+      store_float4x4<kOutMode>(orow, x0, valid, rgb);
+    }
+  }
+  if (!kList) break;
+  __syncthreads();  // every thread has read s_ticket's previous value
+  if (t == 0u) s_ticket = next_ticket;
+  __syncthreads();
+  q = s_ticket;
+  }  // tiles of this workgroup
+}
+
+// ------------------------------------------------------------------ tile light lists (radius cutoff)
+// Wave-uniform bounds of a tile's pixel positions: a padded world-space box and the four side faces of the
+// tile's view pyramid (outward unit normal + offset), plus reach = radius + pad.
+struct TileBounds {
+  float lo[3], hi[3], face[4][4], reach;
+};
+
+__device__ __forceinline__ float lane_value(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+
+// One wave computes the bounds of tile (tile_x, tile_y) from its depth range.  The pixel positions are the
+// images of points of the clip-space box [xa,xb] x [ya,yb] x [dmin,dmax] under the projective map inverseVP;
+// with w > 0 on all eight corners their hull contains them all.
+__device__ __forceinline__ TileBounds tile_bounds(const DeferredParams& p, uint32_t tile_x, uint32_t tile_y, float dmin, float dmax, uint32_t lane) {
+  const float xa = (float)(tile_x * 32u) / (float)p.width * 2.0f - 1.0f;
+  const float xb = (float)min(tile_x * 32u + 32u, p.width) / (float)p.width * 2.0f - 1.0f;
+  const float ya = (float)(tile_y * 32u + p.row_offset) / (float)p.full_height * 2.0f - 1.0f;
+  const float yb = (float)(min(tile_y * 32u + 32u, p.height) + p.row_offset) / (float)p.full_height * 2.0f - 1.0f;
+  // Twelve points, one per lane: lane 4*kind + c holds corner c (xa ya, xb ya, xb yb, xa yb) at depth dmin
+  // (kind 0, the near points), dmax (kind 1, the far points) or dmin - 0.25 (kind 2, a second point of the
+  // same pixel ray).  Lanes from 12 up repeat them.
+  const uint32_t c = lane & 3u, kind = (lane >> 2) % 3u;
+  const float pcx = (c == 1u || c == 2u) ? xb : xa;
+  const float pcy = (c >= 2u) ? yb : ya;
+  const float pcz = kind == 0u ? dmin : (kind == 1u ? dmax : dmin - 0.25f);
+  const float* M = p.inv_vp;
+  const float wx = ((M[0] * pcx + M[4] * pcy) + M[8] * pcz) + M[12];
+  const float wy = ((M[1] * pcx + M[5] * pcy) + M[9] * pcz) + M[13];
+  const float wz = ((M[2] * pcx + M[6] * pcy) + M[10] * pcz) + M[14];
+  const float ww = ((M[3] * pcx + M[7] * pcy) + M[11] * pcz) + M[15];
+  const float q[3] = {wx / ww, wy / ww, wz / ww};
+  const bool ok = (ww > 1e-30f) && (fabsf(q[0]) < 1e30f) && (fabsf(q[1]) < 1e30f) && (fabsf(q[2]) < 1e30f);
+  const bool sane = (__ballot(ok) & 0xFFFull) == 0xFFFull;
+  // box over the near and far points: lanes 0..7, which the xor offsets 1, 2, 4 keep among themselves
+  float box_lo[3], box_hi[3];
+  float scale = 0.0f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    box_lo[a] = q[a];
+    box_hi[a] = q[a];
+#pragma unroll
+    for (int off = 1; off <= 4; off <<= 1) {
+      box_lo[a] = fminf(box_lo[a], __shfl_xor(box_lo[a], off));
+      box_hi[a] = fmaxf(box_hi[a], __shfl_xor(box_hi[a], off));
+    }
+    scale = fmaxf(scale, fmaxf(fabsf(box_lo[a]), fabsf(box_hi[a])));
+  }
+  // binary32 reconstruction error of a position is ~2e-4 relative at the far end of the depth range
+  const float pad = 2e-3f * scale + 1e-2f;
+  // the four side faces of the tile's pyramid, face c in lane c: plane through rays c and c+1, normal pointing
+  // away from ray c+2
+  float near1[3], near2[3], ray[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    near1[a] = __shfl(q[a], (int)((lane + 1u) & 3u));
+    near2[a] = __shfl(q[a], (int)((lane + 2u) & 3u));
+    ray[a] = __shfl(q[a], (int)(8u + c));
+  }
+  const float ux = ray[0] - q[0], uy = ray[1] - q[1], uz = ray[2] - q[2];
+  const float vx = near1[0] - q[0], vy = near1[1] - q[1], vz = near1[2] - q[2];
+  float nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
+  const float len2 = nx * nx + ny * ny + nz * nz;
+  const float inv = len2 > 0.0f ? rsq_(len2) : 0.0f;  // degenerate face: zero normal, never culls
+  nx *= inv; ny *= inv; nz *= inv;
+  const float side = nx * (near2[0] - q[0]) + ny * (near2[1] - q[1]) + nz * (near2[2] - q[2]);
+  const float flip = side > 0.0f ? -1.0f : 1.0f;
+  const float fx = sane ? flip * nx : 0.0f, fy = sane ? flip * ny : 0.0f, fz = sane ? flip * nz : 0.0f;
+  // signed distance of x to the face = dot(n, x) - dot(n, near point c)
+  const float fw = -(fx * q[0] + fy * q[1] + fz * q[2]);
+  TileBounds b;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    b.lo[a] = sane ? lane_value(box_lo[a], 0) - lane_value(pad, 0) : -INFINITY;
+    b.hi[a] = sane ? lane_value(box_hi[a], 0) + lane_value(pad, 0) : INFINITY;
+  }
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    b.face[f][0] = lane_value(fx, f);
+    b.face[f][1] = lane_value(fy, f);
+    b.face[f][2] = lane_value(fz, f);
+    b.face[f][3] = lane_value(fw, f);
+  }
+  b.reach = sqrt_(p.radius2) + lane_value(pad, 0);
+  return b;
+}
+
+// One wave per 32 x 32 pixel tile (four tiles per workgroup; nothing is shared between the waves but the queue
+// push at the end).  Lane l owns the 4-pixel groups (4*(l&7) .. +3, (l>>3) + 8k), k = 0..3, of the tile: four
+// 128-bit depth loads and four albedo loads in flight per lane.  The wave derives the tile's bounds from its
+// depth range, tests the tile's candidates (the lights of its coarse bin when the launch carries bins, else the
+// whole table) 64 at a time and writes the indices of those that can reach the tile, in table order, to the
+// tile's list.  A tile that no light reaches is finished here: every light sum of deferred.comp:120-129 is
+// zero for its pixels, whatever their positions and normals are, so they are their ambient term
+// (deferred.comp:107) - 12 bytes per pixel instead of 24, and the shading kernel never sees the tile.  The other
+// tiles are queued for deferred_kernel<.., true, true>.
+template <int kOutMode>
+__global__ __launch_bounds__(256) void tile_lists_kernel(const DeferredParams p, const TileListOut o) {
+  __shared__ uint32_t s_lit[4], s_class[4];
+  const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+  const uint32_t n_tiles = p.tiles_x * p.tiles_y;
+  const uint32_t tile = blockIdx.x * 4u + wv;
+  if (blockIdx.x == 0u && t <= kListClasses) o.counters_next[t] = 0u;  // queue lengths and ticket of the launch after this one
+  uint32_t lit_tile = 0xFFFFFFFFu, lit_class = 0u;
+  if (tile < n_tiles) {  // wave-uniform
+    const uint32_t tile_y = tile / p.tiles_x, tile_x = tile - tile_y * p.tiles_x;
+    const uint32_t x0 = tile_x * 32u + (lane & 7u) * 4u;
+    float4 dep[4];
+    uint4 alb[4];
+    bool in[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t y = tile_y * 32u + (lane >> 3) + 8u * k;
+      in[k] = (x0 < p.width) && (y < p.height);
+      const uint32_t lx = in[k] ? x0 : tile_x * 32u, ly = in[k] ? y : tile_y * 32u;
+      dep[k] = *reinterpret_cast<const float4*>(p.depth + (size_t)ly * p.pitch_depth + (size_t)lx * 4u);
+      // read once, and only of use when the tile turns out dark: streaming load
+      alb[k] = load_stream_u4(p.albedo + (size_t)ly * p.pitch_albedo + (size_t)lx * 4u);
+    }
+    // depth range over the whole 4-pixel groups, as the shading lanes read them (a group's padding pixels
+    // included: they only widen the bounds)
+    float dmin = INFINITY, dmax = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      dmin = fminf(dmin, fminf(fminf(dep[k].x, dep[k].y), fminf(dep[k].z, dep[k].w)));
+      dmax = fmaxf(dmax, fmaxf(fmaxf(dep[k].x, dep[k].y), fmaxf(dep[k].z, dep[k].w)));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      dmin = fminf(dmin, __shfl_xor(dmin, off));
+      dmax = fmaxf(dmax, __shfl_xor(dmax, off));
+    }
+    const TileBounds b = tile_bounds(p, tile_x, tile_y, dmin, dmax, lane);
+
+    const float4* __restrict__ lights = reinterpret_cast<const float4*>(p.lights);
+    const uint32_t L = p.light_count;
+    const uint32_t bin_index = (tile_y * 32u / kBinPixels) * p.bins_x + tile_x * 32u / kBinPixels;
+    const uint32_t* __restrict__ bin = p.bin_list ? p.bin_list + (size_t)bin_index * L : nullptr;
+    const uint32_t LL = bin ? p.bin_count[bin_index] : L;
+    uint16_t* __restrict__ list = o.tile_list + (size_t)tile * p.list_cap;
+    uint32_t count = 0;  // wave-uniform
+    constexpr uint32_t kBatch = 4;  // groups of 64 candidates in flight
+    for (uint32_t base = 0; base < LL; base += 64u * kBatch) {
+      uint32_t idx[kBatch];
+      float4 lp[kBatch];
+#pragma unroll
+      for (uint32_t u = 0; u < kBatch; ++u) {
+        const uint32_t pos = min(base + u * 64u + lane, LL - 1u);
+        idx[u] = bin ? bin[pos] : pos;
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < kBatch; ++u) lp[u] = lights[3u * idx[u]];
+#pragma unroll
+      for (uint32_t u = 0; u < kBatch; ++u) {
+        const uint32_t pos = base + u * 64u + lane;
+        const float dx = fmaxf(fmaxf(b.lo[0] - lp[u].x, lp[u].x - b.hi[0]), 0.0f);
+        const float dy = fmaxf(fmaxf(b.lo[1] - lp[u].y, lp[u].y - b.hi[1]), 0.0f);
+        const float dz = fmaxf(fmaxf(b.lo[2] - lp[u].z, lp[u].z - b.hi[2]), 0.0f);
+        bool hit = (pos < LL) & ((dx * dx + dy * dy + dz * dz) < p.radius2);  // NaN position: never contributes, never listed
+        if (__ballot(hit) != 0ull) {  // the box rejects most lights of most groups: one uniform branch skips the face tests
+#pragma unroll
+          for (int f = 0; f < 4; ++f)  // outside a side face by more than the radius: cannot reach any pixel of the tile
+            hit &= !(((b.face[f][0] * lp[u].x + b.face[f][1] * lp[u].y) + b.face[f][2] * lp[u].z) + b.face[f][3] > b.reach);
+        }
+        const uint64_t hits = __ballot(hit);
+        if (hit) {
+          const uint32_t k = count + __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u));
+          if (k < p.list_cap) list[k] = (uint16_t)idx[u];
+        }
+        count += (uint32_t)__popcll(hits);
+      }
+    }
+    if (lane == 0u) o.tile_count[tile] = count > p.list_cap ? (count | kTileOverflow) : count;
+    if (count != 0u) {
+      lit_tile = tile;
+      lit_class = count > p.list_cap ? kListClasses - 1u : list_class(count);
     } else {
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
-        if ((uint32_t)i < valid) o[i] = packed[i];
-    }
-  } else {
-    float rgb[4][3];
+      for (int k = 0; k < 4; ++k) {
+        if (!in[k]) continue;
+        const uint32_t y = tile_y * 32u + (lane >> 3) + 8u * k;
+        const uint32_t valid = min(4u, p.width - x0);
+        uint8_t* orow = p.out + (size_t)y * p.pitch_out;
+        const uint32_t words[4] = {alb[k].x, alb[k].y, alb[k].z, alb[k].w};
+        float rgb[4][3];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int row = k == 0 ? kRowAlbedo : k == 1 ? kRowMaterial : kRowExtra;
-        rgb[i][k] = __uint_as_float(s_stash[row + i][t]);
-        rgb[2 + i][k] = last[i][k];
-      }
-    if (kOutMode == kOutRgba16f) {
-      uint2* o = reinterpret_cast<uint2*>(orow) + x0;
+          for (int ch = 0; ch < 3; ++ch) rgb[i][ch] = kAmbient * unorm8(words[i], ch);
+        if (kOutMode == kOutRgba8) {
+          uint32_t packed[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if ((uint32_t)i < valid) {
-          const __half2 a = __floats2half2_rn(rgb[i][0], rgb[i][1]);
-          const __half2 b = __floats2half2_rn(rgb[i][2], 1.0f);
-          o[i] = make_uint2(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b));
+          for (int i = 0; i < 4; ++i)
+            packed[i] = quantize_unorm8(rgb[i][0]) | (quantize_unorm8(rgb[i][1]) << 8) | (quantize_unorm8(rgb[i][2]) << 16) | 0xFF000000u;
+          store_rgba8x4(orow, x0, valid, packed);
+        } else {
+          store_float4x4<kOutMode>(orow, x0, valid, rgb);
         }
       }
-    } else {
-      float4* o = reinterpret_cast<float4*>(orow) + x0;
+    }
+  }
+  if (lane == 0u) {
+    s_lit[wv] = lit_tile;
+    s_class[wv] = lit_class;
+  }
+  __syncthreads();
+  if (t < kListClasses) {  // thread c queues this workgroup's tiles of class c: one atomic for all of them
+    uint32_t n = 0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if ((uint32_t)i < valid) o[i] = make_float4(rgb[i][0], rgb[i][1], rgb[i][2], 1.0f);
+    for (int w = 0; w < 4; ++w) n += (s_lit[w] != 0xFFFFFFFFu && s_class[w] == t) ? 1u : 0u;
+    if (n != 0u) {
+      uint32_t slot = atomicAdd(o.counters_now + t, n);
+      uint32_t* queue = o.lit_queue + (size_t)t * n_tiles;
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        if (s_lit[w] != 0xFFFFFFFFu && s_class[w] == t) queue[slot++] = s_lit[w];
     }
   }
 }
@@ -805,43 +873,66 @@ __global__ __launch_bounds__(256) void light_bins_kernel(const DeferredParams p,
   uint32_t* __restrict__ list = bin_list + (size_t)b * L;
   const float radius = sqrt_(p.radius2);
   uint32_t count = 0;  // block-uniform
-  for (uint32_t base = 0; base < L; base += 256u) {
-    const uint32_t i = base + t;
-    bool hit = i < L;
-    if (hit) {
-      const float4 lp = lights[3u * i];
-      const float scale = fmaxf(fmaxf(fabsf(lp.x), fabsf(lp.y)), fabsf(lp.z)) + radius;
-      const float reach = radius + (2e-3f * scale + 1e-2f);
+  // The positions of kBinBatch trips are requested together: a workgroup walks the whole table alone, so its run
+  // time is the number of dependent memory round trips, not the bytes.
+  constexpr uint32_t kBinBatch = 8;
+  for (uint32_t base0 = 0; base0 < L; base0 += 256u * kBinBatch) {
+    float4 lps[kBinBatch];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) hit &= !(((s_face[4 * c] * lp.x + s_face[4 * c + 1] * lp.y) + s_face[4 * c + 2] * lp.z) + s_face[4 * c + 3] > reach);
+    for (uint32_t u = 0; u < kBinBatch; ++u) lps[u] = lights[3u * min(base0 + u * 256u + t, L - 1u)];
+#pragma unroll
+    for (uint32_t u = 0; u < kBinBatch; ++u) {
+      const uint32_t base = base0 + u * 256u;
+      if (base >= L) break;  // block-uniform
+      const uint32_t i = base + t;
+      bool hit = i < L;
+      {
+        const float4 lp = lps[u];
+        const float scale = fmaxf(fmaxf(fabsf(lp.x), fabsf(lp.y)), fabsf(lp.z)) + radius;
+        const float reach = radius + (2e-3f * scale + 1e-2f);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) hit &= !(((s_face[4 * c] * lp.x + s_face[4 * c + 1] * lp.y) + s_face[4 * c + 2] * lp.z) + s_face[4 * c + 3] > reach);
+      }
+      const uint64_t hits = __ballot(hit);
+      __syncthreads();  // every wave is past its previous read of s_cnt
+      if (lane == 0u) s_cnt[wv] = (uint32_t)__popcll(hits);
+      __syncthreads();
+      const uint32_t c0 = s_cnt[0], c1 = s_cnt[1], c2 = s_cnt[2], c3 = s_cnt[3];
+      const uint32_t before = count + (wv > 0u ? c0 : 0u) + (wv > 1u ? c1 : 0u) + (wv > 2u ? c2 : 0u);
+      if (hit) list[before + __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u))] = i;
+      count += (c0 + c1) + (c2 + c3);
     }
-    const uint64_t hits = __ballot(hit);
-    __syncthreads();  // every wave is past its previous read of s_cnt
-    if (lane == 0u) s_cnt[wv] = (uint32_t)__popcll(hits);
-    __syncthreads();
-    const uint32_t c0 = s_cnt[0], c1 = s_cnt[1], c2 = s_cnt[2], c3 = s_cnt[3];
-    const uint32_t before = count + (wv > 0u ? c0 : 0u) + (wv > 1u ? c1 : 0u) + (wv > 2u ? c2 : 0u);
-    if (hit) list[before + __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u))] = i;
-    count += (c0 + c1) + (c2 + c3);
   }
   if (t == 0u) bin_count[b] = count;
 }
 
-template <int kOutMode>
-hipError_t launch_mode(const DeferredParams& p, hipStream_t stream) {
-  const dim3 grid((p.width + 31u) / 32u, (p.height + 31u) / 32u, 1u);
-  const bool radius = (p.flags & 1u) != 0u, no_tile = (p.flags & 2u) != 0u;
-  if (!radius)
-    hipLaunchKernelGGL((deferred_kernel<kOutMode, false, false>), grid, dim3(256), 0, stream, p);
-  else if (no_tile)
-    hipLaunchKernelGGL((deferred_kernel<kOutMode, true, false>), grid, dim3(256), 0, stream, p);
-  else
-    hipLaunchKernelGGL((deferred_kernel<kOutMode, true, true>), grid, dim3(256), 0, stream, p);
-  return hipGetLastError();
-}
-
 constexpr uint32_t kBinMinLights = 256;           // below this every tile tests the whole table: nothing to gain
 constexpr uint64_t kBinMaxEntries = 64ull << 20;  // 256 MiB of indices
+constexpr uint32_t kListCap = kChunk;             // entries per tile list: one LDS chunk
+constexpr uint32_t kListMaxLights = 65536;        // list entries are 16-bit light indices
+
+template <int kOutMode>
+hipError_t launch_mode(const DeferredParams& p, const TileListOut* lists, uint32_t cu_count, hipStream_t stream) {
+  const dim3 grid((p.width + 31u) / 32u, (p.height + 31u) / 32u, 1u);
+  const bool radius = (p.flags & 1u) != 0u;
+  if (!radius) {
+    hipLaunchKernelGGL((deferred_kernel<kOutMode, false, false>), grid, dim3(256), 0, stream, p);
+  } else if (!lists) {
+    hipLaunchKernelGGL((deferred_kernel<kOutMode, true, false>), grid, dim3(256), 0, stream, p);
+  } else {
+    const uint32_t tiles = p.tiles_x * p.tiles_y;
+    hipLaunchKernelGGL((tile_lists_kernel<kOutMode>), dim3((tiles + 3u) / 4u), dim3(256), 0, stream, p, *lists);
+    if (hipError_t e = hipGetLastError()) return e;
+    // the list-shading workgroups stride over the queue of lit tiles: as many as stay resident together
+    static const uint32_t per_cu = [] {
+      int n = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, deferred_kernel<kOutMode, true, true>, 256, 0) != hipSuccess || n < 1) n = 3;
+      return (uint32_t)n;
+    }();
+    hipLaunchKernelGGL((deferred_kernel<kOutMode, true, true>), dim3(min(tiles, cu_count * per_cu)), dim3(256), 0, stream, p);
+  }
+  return hipGetLastError();
+}
 
 }  // namespace
 
@@ -850,32 +941,81 @@ hipError_t vkr_launch_exact_div_check(uint32_t n, uint32_t seed, uint32_t* misma
   return hipGetLastError();
 }
 
-uint64_t vkr_deferred_bin_entries(const DeferredParams& p) {
-  const bool tiled = (p.flags & 1u) != 0u && (p.flags & 2u) == 0u;
-  if (!tiled || p.light_count < kBinMinLights) return 0;
-  const uint64_t bins = (uint64_t)((p.width + kBinPixels - 1u) / kBinPixels) * ((p.height + kBinPixels - 1u) / kBinPixels);
-  const uint64_t entries = bins * p.light_count;
-  return entries <= kBinMaxEntries ? entries : 0;
+TiledLayout vkr_deferred_tiled_layout(const DeferredParams& p) {
+  TiledLayout t{};
+  const bool tiled = (p.flags & 1u) != 0u && (p.flags & 2u) == 0u && p.light_count <= kListMaxLights && p.width != 0u && p.height != 0u;
+  if (!tiled) return t;
+  t.tiled = true;
+  t.tiles_x = (p.width + 31u) / 32u;
+  t.tiles_y = (p.height + 31u) / 32u;
+  t.list_cap = kListCap;
+  const uint64_t tiles = (uint64_t)t.tiles_x * t.tiles_y;
+  auto up = [](uint64_t v) { return (v + 255u) / 256u * 256u; };
+  uint64_t off = 0;
+  if (p.light_count >= kBinMinLights) {
+    t.bins_x = (p.width + kBinPixels - 1u) / kBinPixels;
+    t.bins = (uint64_t)t.bins_x * ((p.height + kBinPixels - 1u) / kBinPixels);
+    t.bin_entries = t.bins * p.light_count;
+    if (t.bin_entries > kBinMaxEntries) t.bins = t.bin_entries = 0, t.bins_x = 0;
+  }
+  t.off_bin_list = off;
+  off += up(t.bin_entries * 4u);
+  t.off_bin_count = off;
+  off += up(t.bins * 4u);
+  t.off_tile_count = off;
+  off += up(tiles * 4u);
+  t.off_lit_queue = off;
+  off += up(tiles * 4u * kListClasses);
+  t.off_tile_list = off;
+  off += up(tiles * t.list_cap * 2u);
+  t.total_bytes = off;
+  return t;
 }
 
-hipError_t vkr_launch_deferred(const DeferredParams& params, uint32_t* bins, hipStream_t stream) {
+hipError_t vkr_launch_deferred(const DeferredParams& params, void* tiled_ws, uint32_t* counters, uint32_t epoch, uint32_t cu_count,
+                               hipStream_t stream) {
   DeferredParams p = params;
   p.bin_list = nullptr;
   p.bin_count = nullptr;
   p.bins_x = 0;
-  const uint64_t entries = vkr_deferred_bin_entries(p);
-  if (bins && entries != 0u) {
-    const dim3 bin_grid((p.width + kBinPixels - 1u) / kBinPixels, (p.height + kBinPixels - 1u) / kBinPixels, 1u);
-    hipLaunchKernelGGL(light_bins_kernel, bin_grid, dim3(256), 0, stream, p, bins, bins + entries);
-    if (hipError_t e = hipGetLastError()) return e;
-    p.bin_list = bins;
-    p.bin_count = bins + entries;
-    p.bins_x = bin_grid.x;
+  p.tile_list = nullptr;
+  p.tile_count = nullptr;
+  p.lit_queue = nullptr;
+  p.lit_counters = nullptr;
+  p.tiles_x = (p.width + 31u) / 32u;
+  p.tiles_y = (p.height + 31u) / 32u;
+  p.list_cap = 0;
+  const TiledLayout t = vkr_deferred_tiled_layout(p);
+  TileListOut lists{};
+  const bool use_lists = t.tiled && tiled_ws && counters;
+  if (t.tiled && !use_lists) return hipErrorInvalidValue;  // the caller provides the workspace of a tiled launch
+  if (use_lists) {
+    uint8_t* ws = static_cast<uint8_t*>(tiled_ws);
+    if (t.bin_entries != 0u) {
+      uint32_t* bin_list = reinterpret_cast<uint32_t*>(ws + t.off_bin_list);
+      uint32_t* bin_count = reinterpret_cast<uint32_t*>(ws + t.off_bin_count);
+      const dim3 bin_grid(t.bins_x, (uint32_t)(t.bins / t.bins_x), 1u);
+      hipLaunchKernelGGL(light_bins_kernel, bin_grid, dim3(256), 0, stream, p, bin_list, bin_count);
+      if (hipError_t e = hipGetLastError()) return e;
+      p.bin_list = bin_list;
+      p.bin_count = bin_count;
+      p.bins_x = t.bins_x;
+    }
+    lists.tile_list = reinterpret_cast<uint16_t*>(ws + t.off_tile_list);
+    lists.tile_count = reinterpret_cast<uint32_t*>(ws + t.off_tile_count);
+    lists.lit_queue = reinterpret_cast<uint32_t*>(ws + t.off_lit_queue);
+    lists.counters_now = counters + (epoch & 1u) * kListCounterStride;
+    lists.counters_next = counters + ((epoch + 1u) & 1u) * kListCounterStride;
+    p.tile_list = lists.tile_list;
+    p.tile_count = lists.tile_count;
+    p.lit_queue = lists.lit_queue;
+    p.lit_counters = lists.counters_now;
+    p.list_cap = t.list_cap;
   }
   switch (p.out_mode) {
-    case kOutRgba8: return launch_mode<kOutRgba8>(p, stream);
-    case kOutRgba16f: return launch_mode<kOutRgba16f>(p, stream);
-    case kOutRgba32f: return launch_mode<kOutRgba32f>(p, stream);
+    case kOutRgba8: return launch_mode<kOutRgba8>(p, use_lists ? &lists : nullptr, cu_count, stream);
+    case kOutRgba16f: return launch_mode<kOutRgba16f>(p, use_lists ? &lists : nullptr, cu_count, stream);
+    case kOutRgba32f: return launch_mode<kOutRgba32f>(p, use_lists ? &lists : nullptr, cu_count, stream);
     default: return hipErrorInvalidValue;
   }
 }

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -186,22 +187,29 @@ int32_t run_deferred(vkr_context* ctx, const vkr_deferred_args* a) {
   p.radius2 = a->push[3] * a->push[3];
   std::memcpy(p.inv_vp, a->push + 4, 64);
   VKR_HIP(hipSetDevice(ctx->device));
-  uint32_t* bins = nullptr;
-  const uint64_t bin_entries = vkr_deferred_bin_entries(p);
-  if (bin_entries != 0u) {
-    const uint32_t bin_count = ((w + kBinPixels - 1u) / kBinPixels) * ((h + kBinPixels - 1u) / kBinPixels);
-    const size_t need = (size_t)(bin_entries + bin_count) * sizeof(uint32_t);
-    if (need > ctx->light_bins_bytes) {
-      // hipFree waits for the device: earlier launches still reading the old bins finish first
-      if (ctx->light_bins) VKR_HIP(hipFree(ctx->light_bins));
-      ctx->light_bins = nullptr;
-      ctx->light_bins_bytes = 0;
-      VKR_HIP(hipMalloc(&ctx->light_bins, need));
-      ctx->light_bins_bytes = need;
+  const TiledLayout layout = vkr_deferred_tiled_layout(p);
+  if (layout.tiled) {
+    if (!ctx->tile_counters) {
+      VKR_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->tile_counters), 256));
+      VKR_HIP(hipMemsetAsync(ctx->tile_counters, 0, 256, ctx->stream));
     }
-    bins = static_cast<uint32_t*>(ctx->light_bins);
+    if (layout.total_bytes > ctx->tiled_ws_bytes) {
+      // hipFree waits for the device: earlier launches still reading the old lists finish first
+      if (ctx->tiled_ws) VKR_HIP(hipFree(ctx->tiled_ws));
+      ctx->tiled_ws = nullptr;
+      ctx->tiled_ws_bytes = 0;
+      VKR_HIP(hipMalloc(&ctx->tiled_ws, layout.total_bytes));
+      ctx->tiled_ws_bytes = layout.total_bytes;
+    }
   }
-  VKR_HIP(vkr_launch_deferred(p, bins, ctx->stream));
+  VKR_HIP(vkr_launch_deferred(p, ctx->tiled_ws, ctx->tile_counters, ctx->tile_epoch, (uint32_t)ctx->props.multiProcessorCount, ctx->stream));
+  if (layout.tiled) {
+    ctx->tile_epoch += 1u;
+    ctx->last_tiled = layout;
+    ctx->last_width = w;
+    ctx->last_height = h;
+    ctx->last_lights = a->light_count;
+  }
   return VKR_OK;
 }
 
@@ -384,7 +392,8 @@ int32_t vkr_context_destroy(vkr_context* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamDestroy(ctx->stream);
   }
-  if (ctx->light_bins) (void)hipFree(ctx->light_bins);
+  if (ctx->tiled_ws) (void)hipFree(ctx->tiled_ws);
+  if (ctx->tile_counters) (void)hipFree(ctx->tile_counters);
   delete ctx;
   return VKR_OK;
 }
@@ -513,6 +522,43 @@ int32_t vkr_buffer_fill_u32(vkr_buffer* buf, uint64_t offset, uint32_t value, ui
 }
 
 int32_t vkr_deferred_resolve(vkr_context* ctx, const vkr_deferred_args* args) { return run_deferred(ctx, args); }
+
+int32_t vkr_deferred_tile_stats(vkr_context* ctx, vkr_tile_stats* out) {
+  if (!ctx || !out) return fail(VKR_ERR_INVALID_ARGUMENT, "vkr_deferred_tile_stats: null argument");
+  std::memset(out, 0, sizeof(*out));
+  const TiledLayout& t = ctx->last_tiled;
+  if (!t.tiled || !ctx->tiled_ws) return fail(VKR_ERR_BAD_STATE, "no resolve with light lists has run on this context");
+  const uint64_t tiles = (uint64_t)t.tiles_x * t.tiles_y;
+  std::unique_ptr<uint32_t[]> counts(new (std::nothrow) uint32_t[tiles]);
+  std::unique_ptr<uint32_t[]> bin_counts(t.bins ? new (std::nothrow) uint32_t[t.bins] : nullptr);
+  if (!counts || (t.bins && !bin_counts)) return fail(VKR_ERR_OUT_OF_MEMORY, "out of host memory");
+  VKR_HIP(hipSetDevice(ctx->device));
+  const uint8_t* ws = static_cast<const uint8_t*>(ctx->tiled_ws);
+  VKR_HIP(hipMemcpyAsync(counts.get(), ws + t.off_tile_count, tiles * 4u, hipMemcpyDeviceToHost, ctx->stream));
+  if (t.bins) VKR_HIP(hipMemcpyAsync(bin_counts.get(), ws + t.off_bin_count, t.bins * 4u, hipMemcpyDeviceToHost, ctx->stream));
+  VKR_HIP(hipStreamSynchronize(ctx->stream));
+  out->tiles = (uint32_t)tiles;
+  out->list_cap = t.list_cap;
+  out->pixels = (uint64_t)ctx->last_width * ctx->last_height;
+  for (uint32_t ty = 0; ty < t.tiles_y; ++ty) {
+    for (uint32_t tx = 0; tx < t.tiles_x; ++tx) {
+      const uint32_t word = counts[(uint64_t)ty * t.tiles_x + tx];
+      const uint64_t px = (uint64_t)std::min(32u, ctx->last_width - tx * 32u) * std::min(32u, ctx->last_height - ty * 32u);
+      uint64_t walked = word;
+      if (word == 0u) {
+        out->dark_tiles += 1u;
+      } else if (word & kTileOverflow) {
+        out->overflow_tiles += 1u;
+        walked = t.bins ? bin_counts[(uint64_t)(ty * 32u / kBinPixels) * t.bins_x + tx * 32u / kBinPixels] : ctx->last_lights;
+      } else {
+        out->listed_tiles += 1u;
+        if (word > out->max_list) out->max_list = word;
+      }
+      out->light_pixels += walked * px;
+    }
+  }
+  return VKR_OK;
+}
 int32_t vkr_prep_indirect(vkr_context* ctx, const vkr_cull_args* args) { return run_cull(ctx, args); }
 uint64_t vkr_cull_workspace_bytes(uint64_t instance_count, uint32_t mesh_count) { return vkr_cull_workspace_size(instance_count, mesh_count); }
 

@@ -5,13 +5,20 @@
 #include <stdint.h>
 
 #include "vkr_c.h"
+#include "vkr_kernels.h"
 
 struct vkr_context {
   int device = 0;
   hipStream_t stream = nullptr;
   hipDeviceProp_t props{};
-  void* light_bins = nullptr;  // coarse light bins of the tiled resolve; grows on demand, freed with the context
-  size_t light_bins_bytes = 0;
+  // Radius-cutoff resolve with light lists: coarse bins, per-tile lists and the lit-tile queue live in one
+  // allocation that grows on demand and is freed with the context; the two alternating queue counters in another.
+  void* tiled_ws = nullptr;
+  size_t tiled_ws_bytes = 0;
+  uint32_t* tile_counters = nullptr;
+  uint32_t tile_epoch = 0;           // tiled launches made so far
+  TiledLayout last_tiled{};          // layout, extent and light count of the most recent one (vkr_deferred_tile_stats)
+  uint32_t last_width = 0, last_height = 0, last_lights = 0;
 };
 
 // Records the message returned by vkr_last_error() for the calling thread and returns `code`.

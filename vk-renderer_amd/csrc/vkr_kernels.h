@@ -25,20 +25,50 @@ struct DeferredParams {
   float cam[3];
   float radius2;
   float inv_vp[16];            // column-major
-  // Tile light lists, optional coarse level: for every kBinPixels x kBinPixels pixel bin the ascending
-  // indices of the lights whose sphere of influence can reach the bin's view pyramid.  bin_list == null:
-  // every tile tests the whole table.
+  // Radius cutoff with light lists.  Coarse level, optional: for every kBinPixels x kBinPixels pixel bin the
+  // ascending indices of the lights whose sphere of influence can reach the bin's view pyramid
+  // (bin_list == null: every tile tests the whole table).  Fine level: per 32 x 32 pixel tile the ascending
+  // indices of the lights that can reach the tile, and the queue of tiles that have any.
   const uint32_t* bin_list;    // bins_x * bins_y * light_count entries, bin-major
   const uint32_t* bin_count;   // entries used per bin
   uint32_t bins_x;
+  uint32_t tiles_x, tiles_y;   // ceil(width / 32), ceil(height / 32)
+  uint32_t list_cap;           // entries per tile list
+  const uint16_t* tile_list;   // tiles_x * tiles_y * list_cap
+  const uint32_t* tile_count;  // per tile: list length; kTileOverflow set: the list holds only its first list_cap entries
+  const uint32_t* lit_queue;   // kListClasses queues of tiles_x * tiles_y entries: the tiles with a non-empty list, by list class
+  const uint32_t* lit_counters; // [c] = length of queue c; [kListClasses] = ticket counter of the shading launch
 };
 
 constexpr uint32_t kBinPixels = 128;  // 4 x 4 tiles
+constexpr uint32_t kTileOverflow = 0x80000000u;
+constexpr uint32_t kListClasses = 4;         // queues of lit tiles, by list length
+constexpr uint32_t kListCounterStride = 8;   // words per counter set: kListClasses queue lengths, one ticket, padding
 
-// Entries the coarse light bins of a launch need (0 when the launch does not use them).
-uint64_t vkr_deferred_bin_entries(const DeferredParams& p);
-// bins: device memory for vkr_deferred_bin_entries(p) + bins_x * bins_y uint32 words, or null.
-hipError_t vkr_launch_deferred(const DeferredParams& p, uint32_t* bins, hipStream_t stream);
+// What tile_lists_kernel writes.  Queue lengths and ticket live in one of two counter sets that alternate from one
+// tiled launch of a context to the next: a launch works on counters_now (zero on entry) and zeroes
+// counters_next, which nothing reads until the following launch makes it its counters_now.
+struct TileListOut {
+  uint16_t* tile_list;
+  uint32_t* tile_count;
+  uint32_t* lit_queue;
+  uint32_t* counters_now;
+  uint32_t* counters_next;
+};
+
+// Device memory a launch with the radius cutoff and light lists needs (tiled == false: none).
+struct TiledLayout {
+  bool tiled;
+  uint32_t tiles_x, tiles_y, bins_x, list_cap;
+  uint64_t bins, bin_entries;
+  uint64_t off_bin_list, off_bin_count, off_tile_count, off_lit_queue, off_tile_list, total_bytes;
+};
+TiledLayout vkr_deferred_tiled_layout(const DeferredParams& p);
+// tiled_ws: total_bytes of 256-byte-aligned device memory when the layout says tiled, else ignored.
+// counters: 2 x kListCounterStride device words, zero before the context's first tiled launch; epoch: number of tiled launches the
+// context has made so far.  cu_count sizes the grid of the list-shading launch (workgroups that stay resident).
+hipError_t vkr_launch_deferred(const DeferredParams& p, void* tiled_ws, uint32_t* counters, uint32_t epoch, uint32_t cu_count,
+                               hipStream_t stream);
 hipError_t vkr_launch_exact_div_check(uint32_t n, uint32_t seed, uint32_t* mismatches, hipStream_t stream);
 
 struct DrawCmd {
