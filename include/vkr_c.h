@@ -170,8 +170,10 @@ typedef struct vkr_draw_indexed_indirect_command {
   uint32_t firstInstance;
 } vkr_draw_indexed_indirect_command;
 
-#define VKR_CULL_DETERMINISTIC 1u /* visible[] ascending inside each mesh segment (mask -> place);
-                                     default is one atomic per wave and mesh run (segment order unspecified) */
+#define VKR_CULL_DETERMINISTIC 1u /* visible[] ascending inside each mesh segment (one launch; its state, one 64-bit word
+                                     per 1024 instances, lives in context-owned device memory that is allocated or grown
+                                     inside the call and released with the context); default is one atomic per wave and
+                                     mesh run (segment order unspecified) */
 
 /* The pass /root/reference/shaders/prep_indirect.comp:1-5 leaves empty.  Instance i carries a
  * world-space AABB and a mesh id; instances of a mesh are contiguous, as the model-matrix array of
@@ -195,27 +197,24 @@ typedef struct vkr_cull_args {
   const vkr_draw_indexed_indirect_command* cmd_template;   /* device: M */
   vkr_draw_indexed_indirect_command* cmd_out;              /* device: M */
   uint32_t* visible;        /* device: N */
-  uint32_t* error_flag;     /* device, optional: set to 1 if an instance names a mesh outside this call */
-  void* workspace;          /* device, VKR_CULL_DETERMINISTIC only */
-  uint64_t workspace_bytes; /* >= vkr_cull_workspace_bytes(N, M) */
+  uint32_t* error_flag;     /* device, optional: set to 1 if an instance names a mesh outside this call (or, in the
+                               deterministic mode, if the launch could not keep its workgroups resident together) */
 } vkr_cull_args;
 
 VKR_API int32_t vkr_prep_indirect(vkr_context* ctx, const vkr_cull_args* args);
-VKR_API uint64_t vkr_cull_workspace_bytes(uint64_t instance_count, uint32_t mesh_count);
 
 /* No counterpart in the reference.  For callers that cannot allocate device memory or let a library do it
  * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the deterministic
- * cull (visible[] ascending inside each mesh segment, as with VKR_CULL_DETERMINISTIC) with its workspace in
- * a fixed array that is part of the library's GPU code (about 0.94 MiB per GPU, held until the process ends;
- * its address is resolved once per GPU inside vkr_context_create).  Same arguments and results as
- * vkr_prep_indirect; args->workspace / workspace_bytes are ignored and VKR_CULL_DETERMINISTIC is implied.
- * The call makes no hipMalloc / hipFree or other allocating call.  VKR_ERR_INVALID_ARGUMENT if
- * instance_count > VKR_NOALLOC_MAX_INSTANCES or mesh_count > VKR_NOALLOC_MAX_MESHES.
+ * cull (visible[] ascending inside each mesh segment, as with VKR_CULL_DETERMINISTIC) with its state in a
+ * fixed array that is part of the library's GPU code (32 KiB per GPU, held until the process ends; its
+ * address is resolved once per GPU inside vkr_context_create).  Same arguments and results as
+ * vkr_prep_indirect; VKR_CULL_DETERMINISTIC is implied.  The call makes no hipMalloc / hipFree or other
+ * allocating call.  VKR_ERR_INVALID_ARGUMENT if instance_count > VKR_NOALLOC_MAX_INSTANCES.
  * All calls on one GPU share the one array: two calls whose kernels could overlap on a GPU (different
- * contexts or processes' threads on the same device) race; calls on one context are stream-ordered and safe.
- * Nothing in the array has to start at zero: every word a call reads was written by that call. */
+ * contexts, or threads of one process on the same device) race; calls on one context are stream-ordered and
+ * safe.  The array keeps the previous call's words; each call tags its words with a sequence number of its
+ * own, so nothing has to be cleared (the library zeroes the array when the numbers wrap, after 2^30 calls). */
 #define VKR_NOALLOC_MAX_INSTANCES 4194304ull /* 2^22 */
-#define VKR_NOALLOC_MAX_MESHES 65536u
 VKR_API int32_t vkr_prep_indirect_noalloc(vkr_context* ctx, const vkr_cull_args* args);
 
 /* ------------------------------------------------------------------ dispatch surface
@@ -233,7 +232,7 @@ VKR_API int32_t vkr_prep_indirect_noalloc(vkr_context* ctx, const vkr_cull_args*
  * push constants [0,80) = DeferredPushData, optional [80,96) = {flags, row_offset, full_height, 0};
  * dispatch(x, y, 1) with x, y = output extent (the reference dispatches one 1x1x1 group per pixel).
  * Kernel "prep_indirect": set 0 bindings 0..5 = aabb_min, aabb_max, mesh_base, cmd_template,
- * cmd_out, visible buffers, binding 6 (optional) = workspace; push constants [0,96) = planes,
+ * cmd_out, visible buffers; push constants [0,96) = planes,
  * [96,112) = {mesh_count, first_mesh, first_instance, flags}; dispatch(instance_count, 1, 1). */
 VKR_API int32_t vkr_kernel_get(vkr_context* ctx, const char* name, vkr_kernel** out_kernel);
 VKR_API int32_t vkr_kernel_push_constant_size(vkr_kernel* kernel, uint32_t* out_min_bytes, uint32_t* out_max_bytes);

@@ -149,20 +149,18 @@ int main(int argc, char** argv) {
       auto meshBase = loadBinaryFile<uint32_t>(dir + "mesh_base.bin");
       auto cmdTemplate = loadBinaryFile<vkr_draw_indexed_indirect_command>(dir + "cmd_template.bin");
       auto planes = loadBinaryFile<float>(dir + "planes.bin");
-      const uint64_t wsBytes = vkr_cull_workspace_bytes(N, M);
 
       vkr::Shader cullShader{device,
                              vkr::ShaderStageFlagBits::eCompute,
                              "prep_indirect",
                              {{vkr::DescriptorType::eStorageBuffer}, {vkr::DescriptorType::eStorageBuffer}, {vkr::DescriptorType::eStorageBuffer},
-                              {vkr::DescriptorType::eStorageBuffer}, {vkr::DescriptorType::eStorageBuffer}, {vkr::DescriptorType::eStorageBuffer},
-                              {vkr::DescriptorType::eStorageBuffer}},
+                              {vkr::DescriptorType::eStorageBuffer}, {vkr::DescriptorType::eStorageBuffer}, {vkr::DescriptorType::eStorageBuffer}},
                              sizeof(CullPushData)};
       vkr::PipelineLayout cullLayout{{cullShader}};
       vkr::ComputePipeline cullPipeline{cullLayout, cullShader};
       // one multi-segment storage buffer, segments 256-byte aligned like vw::Buffer (vkmemory.cpp:23-30)
       vkr::Buffer ssbo{allocator,
-                       {vkr::byteSize(aabbMin), vkr::byteSize(aabbMax), vkr::byteSize(meshBase), vkr::byteSize(cmdTemplate), vkr::byteSize(cmdTemplate), uint64_t(N) * 4, wsBytes},
+                       {vkr::byteSize(aabbMin), vkr::byteSize(aabbMax), vkr::byteSize(meshBase), vkr::byteSize(cmdTemplate), vkr::byteSize(cmdTemplate), uint64_t(N) * 4},
                        vkr::BufferUse::kStorageBuffer};
       vkr::StagingBuffer staging{allocator, 64u << 20, queue};
       staging.queueBufferCopy(aabbMin, ssbo, ssbo.getSegmentDesc(0).offset);
@@ -174,7 +172,7 @@ int main(int argc, char** argv) {
       auto cullPool = cullLayout.getDescLayouts()[0].createDedicatedPool(1);
       auto& cullSet = cullPool.getSets()[0];
       std::vector<vkr::WriteDescriptorSet> writes;
-      for (uint32_t b = 0; b < 7; ++b) writes.push_back(cullSet.writeBuffers(b, vkr::DescriptorType::eStorageBuffer, ssbo.getSegmentDesc(b)));
+      for (uint32_t b = 0; b < 6; ++b) writes.push_back(cullSet.writeBuffers(b, vkr::DescriptorType::eStorageBuffer, ssbo.getSegmentDesc(b)));
       vkr::updateDescriptorSets(writes);
 
       CullPushData cullPush{};

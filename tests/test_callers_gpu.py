@@ -98,14 +98,12 @@ def test_scene_to_cull_end_to_end(vkr, ctx, synth, oracle, scene_mod):
     cmd_template = ctx.buffer_from(tables["draw_commands"])
     cmd_out, visible = ctx.buffer(m * 20), ctx.buffer(n * 4)
     visible.fill_u32(0xFFFFFFFF)
-    ws = ctx.buffer(max(vkr.lib().vkr_cull_workspace_bytes(n, m), 256))
     a = vkr.CullArgs()
     a.aabb_min, a.aabb_max, a.instance_count = ds.aabb_min.ptr, ds.aabb_max.ptr, n
     a.planes = (C.c_float * 24)(*cam["planes"].reshape(24).tolist())
     a.mesh_base, a.mesh_count = ds.mesh_base.ptr, m
     a.flags = vkr.CULL_DETERMINISTIC
     a.cmd_template, a.cmd_out, a.visible = cmd_template.ptr, cmd_out.ptr, visible.ptr
-    a.workspace, a.workspace_bytes = ws.ptr, ws.nbytes
     ctx.prep_indirect(a)
     ctx.wait_idle()
     mesh = oracle.mesh_aabbs(positions, tables["vertex_base"])

@@ -34,7 +34,7 @@ def test_struct_layouts_match_the_header(vkr):
     assert C.sizeof(vkr.Image2D) == 24
     assert C.sizeof(vkr.DeferredArgs) == 5 * 24 + 8 + 4 + 80 + 16 + 4  # 4 bytes of padding after light_count
     assert vkr.DeferredArgs.push.offset == 132 and vkr.DeferredArgs.row_offset.offset == 212
-    assert C.sizeof(vkr.CullArgs) == 8 + 8 + 8 + 96 + 8 + 16 + 8 * 6
+    assert C.sizeof(vkr.CullArgs) == 8 + 8 + 8 + 96 + 8 + 16 + 8 * 4
     assert vkr.DRAW_CMD_DTYPE.itemsize == 20  # VkDrawIndexedIndirectCommand
 
 
@@ -221,7 +221,7 @@ def test_cull_object_code_has_no_float_fma():
     subprocess.run([tools[1], "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}"],
                    check=True, capture_output=True)
     asm = subprocess.run([tools[2], "-d", co], capture_output=True, text=True, check=True).stdout
-    assert "cull_atomic_kernel" in asm and "cull_mask_kernel" in asm
+    assert "cull_atomic_kernel" in asm and "cull_onepass_kernel" in asm
     assert re.search(r"v_(pk_)?mul_f32", asm) and re.search(r"v_(pk_)?add_f32", asm)
     fused = re.findall(r"\bv_(?:fma|fmac|mad|mac|pk_fma)_(?:f32|legacy_f32|f16)\w*", asm)
     assert fused == [], f"fused multiply-add in cull code: {set(fused)}"

@@ -1,8 +1,8 @@
 """The entry point that allocates nothing, vkr_prep_indirect_noalloc, against the existing deterministic entry
-point (vkr_prep_indirect with VKR_CULL_DETERMINISTIC and a caller-provided workspace), through the C ABI.
-Bar: bit-exact - command buffer byte for byte, compacted list word for word (slots past each mesh's count
-included: neither call writes them), error flag.  Two calls in a row share the library's one static
-workspace per GPU, the second on a smaller input, so anything the larger call left behind would show."""
+point (vkr_prep_indirect with VKR_CULL_DETERMINISTIC, whose state lives in context-owned hipMalloc'd memory),
+through the C ABI.  Bar: bit-exact - command buffer byte for byte, compacted list word for word (slots past
+each mesh's count included: neither call writes them), error flag.  Two calls in a row share the library's
+one static array per GPU, the second on a smaller input, so anything the larger call left behind would show."""
 import numpy as np
 import pytest
 
@@ -18,9 +18,7 @@ def _both(vkr, ctx, scene, planes, **kw):
         cs.cmd_out.fill_u32(0xDEADBEEF, 0, cs.m * 20 // 4 * 4)
         cs.error_flag.fill_u32(0)
         if noalloc:
-            a = cs.args(planes, 0)          # VKR_CULL_DETERMINISTIC is implied
-            a.workspace, a.workspace_bytes = None, 0  # and the workspace arguments are ignored
-            ctx.prep_indirect_noalloc(a)
+            ctx.prep_indirect_noalloc(cs.args(planes, 0))  # VKR_CULL_DETERMINISTIC is implied
         else:
             ctx.prep_indirect(cs.args(planes, vkr.CULL_DETERMINISTIC))
         ctx.wait_idle()
@@ -67,15 +65,11 @@ def test_instance_range_arguments(vkr, synth, ctx):
     _same(want, got)
 
 
-def test_rejects_sizes_beyond_the_static_workspace(vkr, synth, ctx):
+def test_rejects_sizes_beyond_the_static_array(vkr, synth, ctx):
     scene = synth.cull_case(100, 4)
     cs = vkr.CullScene(ctx, scene["aabb_min"], scene["aabb_max"], scene["mesh_base"], scene["cmd_template"])
     a = cs.args(scene["planes"], 0)
     a.instance_count = vkr.NOALLOC_MAX_INSTANCES + 1
-    with pytest.raises(vkr.VkrError, match="exceed the limit"):
-        ctx.prep_indirect_noalloc(a)
-    a = cs.args(scene["planes"], 0)
-    a.mesh_count = vkr.NOALLOC_MAX_MESHES + 1
     with pytest.raises(vkr.VkrError, match="exceed the limit"):
         ctx.prep_indirect_noalloc(a)
     # an unchanged small call still works afterwards

@@ -31,7 +31,6 @@ DEFERRED_RADIUS_CUTOFF = 1
 DEFERRED_NO_TILE_LISTS = 2
 CULL_DETERMINISTIC = 1
 NOALLOC_MAX_INSTANCES = 1 << 22
-NOALLOC_MAX_MESHES = 1 << 16
 LIGHT_STRIDE = 48
 
 DRAW_CMD_DTYPE = np.dtype([("indexCount", "<u4"), ("instanceCount", "<u4"), ("firstIndex", "<u4"),
@@ -68,7 +67,7 @@ class CullArgs(C.Structure):
                 ("planes", C.c_float * 24), ("mesh_base", C.c_void_p), ("mesh_count", C.c_uint32),
                 ("first_mesh", C.c_uint32), ("first_instance", C.c_uint32), ("flags", C.c_uint32),
                 ("cmd_template", C.c_void_p), ("cmd_out", C.c_void_p), ("visible", C.c_void_p),
-                ("error_flag", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64)]
+                ("error_flag", C.c_void_p)]
 
 
 class Camera(C.Structure):
@@ -149,7 +148,6 @@ EXPORTS = {
     "vkr_deferred_resolve": (C.c_int32, [_P, C.POINTER(DeferredArgs)]),
     "vkr_deferred_tile_stats": (C.c_int32, [_P, C.POINTER(TileStats)]),
     "vkr_prep_indirect": (C.c_int32, [_P, C.POINTER(CullArgs)]),
-    "vkr_cull_workspace_bytes": (C.c_uint64, [C.c_uint64, C.c_uint32]),
     "vkr_prep_indirect_noalloc": (C.c_int32, [_P, C.POINTER(CullArgs)]),
     "vkr_kernel_get": (C.c_int32, [_P, C.c_char_p, _PP]),
     "vkr_kernel_push_constant_size": (C.c_int32, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
@@ -447,7 +445,7 @@ class Context:
         _check(lib().vkr_prep_indirect(self.handle, C.byref(args)))
 
     def prep_indirect_noalloc(self, args: CullArgs):
-        """The deterministic cull in the library's static per-GPU workspace: no allocation inside the call."""
+        """The deterministic cull with its state in the library's static per-GPU array: no allocation inside the call."""
         _check(lib().vkr_prep_indirect_noalloc(self.handle, C.byref(args)))
 
     def destroy(self):
@@ -500,7 +498,7 @@ class CullScene:
     """Device-resident inputs and outputs of one cull call."""
 
     def __init__(self, ctx: Context, aabb_min: np.ndarray, aabb_max: np.ndarray, mesh_base: np.ndarray,
-                 cmd_template: np.ndarray, *, first_mesh: int = 0, first_instance: int = 0, deterministic_ws: bool = True):
+                 cmd_template: np.ndarray, *, first_mesh: int = 0, first_instance: int = 0):
         self.ctx = ctx
         self.n = int(np.asarray(aabb_min).reshape(-1, 4).shape[0])
         self.m = int(np.asarray(mesh_base).shape[0])
@@ -513,8 +511,6 @@ class CullScene:
         self.visible = ctx.buffer(max(self.n * 4, 16))
         self.error_flag = ctx.buffer(16)
         self.error_flag.fill_u32(0)
-        ws = lib().vkr_cull_workspace_bytes(self.n, self.m)
-        self.workspace = ctx.buffer(max(ws, 256)) if deterministic_ws else None
 
     def args(self, planes: np.ndarray, flags: int = 0) -> CullArgs:
         a = CullArgs()
@@ -524,8 +520,6 @@ class CullScene:
         a.first_mesh, a.first_instance, a.flags = self.first_mesh, self.first_instance, flags
         a.cmd_template, a.cmd_out, a.visible = self.cmd_template.ptr, self.cmd_out.ptr, self.visible.ptr
         a.error_flag = self.error_flag.ptr
-        if self.workspace is not None:
-            a.workspace, a.workspace_bytes = self.workspace.ptr, self.workspace.nbytes
         return a
 
     def run(self, planes: np.ndarray, flags: int = 0):

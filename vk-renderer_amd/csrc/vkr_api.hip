@@ -213,12 +213,12 @@ int32_t run_deferred(vkr_context* ctx, const vkr_deferred_args* a) {
   return VKR_OK;
 }
 
-// static_ws != null: the allocation-free entry point; the deterministic kernels run in that workspace.
-int32_t run_cull(vkr_context* ctx, const vkr_cull_args* a, void* static_ws = nullptr, uint64_t static_ws_bytes = 0) {
+// static_state: the allocation-free entry point runs the deterministic kernel in the library's per-GPU array.
+int32_t run_cull(vkr_context* ctx, const vkr_cull_args* a, bool static_state = false) {
   if (!ctx || !a) return fail(VKR_ERR_INVALID_ARGUMENT, "vkr_prep_indirect: null argument");
   if (a->instance_count >= (1ull << 31)) return fail(VKR_ERR_INVALID_ARGUMENT, "instance_count %llu >= 2^31", (unsigned long long)a->instance_count);
   if (a->flags & ~VKR_CULL_DETERMINISTIC) return fail(VKR_ERR_INVALID_ARGUMENT, "unknown flags 0x%x", a->flags);
-  static_assert(VKR_NOALLOC_MAX_INSTANCES == kCullStaticMaxInstances && VKR_NOALLOC_MAX_MESHES == kCullStaticMaxMeshes, "header limits = kernel limits");
+  static_assert(VKR_NOALLOC_MAX_INSTANCES == kCullStaticMaxInstances, "header limit = kernel limit");
   if (a->mesh_count == 0u) {
     if (a->instance_count != 0u) return fail(VKR_ERR_INVALID_ARGUMENT, "instances without meshes");
     return VKR_OK;
@@ -236,25 +236,39 @@ int32_t run_cull(vkr_context* ctx, const vkr_cull_args* a, void* static_ws = nul
   p.cmd_out = reinterpret_cast<DrawCmd*>(a->cmd_out);
   p.visible = a->visible;
   p.error_flag = a->error_flag;
-  p.workspace = a->workspace;
   p.instance_count = (uint32_t)a->instance_count;
   p.mesh_count = a->mesh_count;
   p.first_mesh = a->first_mesh;
   p.first_instance = a->first_instance;
   std::memcpy(p.planes, a->planes, sizeof(p.planes));
   VKR_HIP(hipSetDevice(ctx->device));
-  if (static_ws) {
-    if (vkr_cull_workspace_size(a->instance_count, a->mesh_count) > static_ws_bytes)
-      return fail(VKR_ERR_INVALID_ARGUMENT, "static workspace too small for %llu instances, %u meshes", (unsigned long long)a->instance_count, a->mesh_count);
-    p.workspace = static_ws;
-    VKR_HIP(vkr_launch_cull_deterministic(p, ctx->stream));
+  const uint32_t resident = (uint32_t)ctx->props.multiProcessorCount * vkr_cull_blocks_per_cu();
+  const uint64_t need = vkr_cull_state_bytes(a->instance_count);
+  if (static_state) {
+    uint64_t bytes = 0;
+    uint32_t seq = 0;
+    bool clear_first = false;
+    void* state = vkr_cull_static_state(ctx->device, &bytes, &seq, &clear_first);
+    if (!state) return fail(VKR_ERR_BAD_STATE, "vkr_prep_indirect_noalloc: the static state of device %d was not resolved at context creation", ctx->device);
+    if (need > bytes) return fail(VKR_ERR_INVALID_ARGUMENT, "static state too small for %llu instances", (unsigned long long)a->instance_count);
+    if (clear_first) VKR_HIP(hipMemsetAsync(state, 0, bytes, ctx->stream));
+    VKR_HIP(vkr_launch_cull_deterministic(p, state, seq, resident, ctx->stream));
   } else if (a->flags & VKR_CULL_DETERMINISTIC) {
-    const uint64_t need = vkr_cull_workspace_size(a->instance_count, a->mesh_count);
-    if (!a->workspace || a->workspace_bytes < need)
-      return fail(VKR_ERR_INVALID_ARGUMENT, "deterministic cull needs a %llu-byte workspace (got %llu)", (unsigned long long)need,
-                  (unsigned long long)a->workspace_bytes);
-    if (reinterpret_cast<uintptr_t>(a->workspace) & 255u) return fail(VKR_ERR_INVALID_ARGUMENT, "workspace must be 256-byte aligned");
-    VKR_HIP(vkr_launch_cull_deterministic(p, ctx->stream));
+    if (need > ctx->cull_state_bytes) {
+      // hipFree waits for the device: an earlier launch still using the old state finishes first
+      if (ctx->cull_state) VKR_HIP(hipFree(ctx->cull_state));
+      ctx->cull_state = nullptr;
+      ctx->cull_state_bytes = 0;
+      VKR_HIP(hipMalloc(&ctx->cull_state, need));
+      ctx->cull_state_bytes = need;
+      ctx->cull_seq = 0;
+    }
+    if (ctx->cull_state && (ctx->cull_seq == 0u || ctx->cull_seq + 1u >= kCullSeqEnd)) {  // fresh memory, or every sequence number has been used
+      VKR_HIP(hipMemsetAsync(ctx->cull_state, 0, ctx->cull_state_bytes, ctx->stream));
+      ctx->cull_seq = 0;
+    }
+    ctx->cull_seq += 1u;
+    VKR_HIP(vkr_launch_cull_deterministic(p, ctx->cull_state, ctx->cull_seq, resident, ctx->stream));
   } else {
     VKR_HIP(vkr_launch_cull_atomic(p, ctx->stream));
   }
@@ -338,11 +352,6 @@ int32_t replay(vkr_context* ctx, const Dispatch& d) {
   a.cmd_out = static_cast<vkr_draw_indexed_indirect_command*>(ptr);
   if ((rc = buffer_ptr(s.buffers[0][5], "visible", n * 4, &ptr)) != VKR_OK) return rc;
   a.visible = static_cast<uint32_t*>(ptr);
-  if (s.buffers[0][6].buf) {
-    if ((rc = buffer_ptr(s.buffers[0][6], "workspace", 0, &ptr)) != VKR_OK) return rc;
-    a.workspace = ptr;
-    a.workspace_bytes = s.buffers[0][6].range;
-  }
   return run_cull(ctx, &a);
 }
 
@@ -392,6 +401,7 @@ int32_t vkr_context_destroy(vkr_context* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamDestroy(ctx->stream);
   }
+  if (ctx->cull_state) (void)hipFree(ctx->cull_state);
   if (ctx->tiled_ws) (void)hipFree(ctx->tiled_ws);
   if (ctx->tile_counters) (void)hipFree(ctx->tile_counters);
   delete ctx;
@@ -560,20 +570,12 @@ int32_t vkr_deferred_tile_stats(vkr_context* ctx, vkr_tile_stats* out) {
   return VKR_OK;
 }
 int32_t vkr_prep_indirect(vkr_context* ctx, const vkr_cull_args* args) { return run_cull(ctx, args); }
-uint64_t vkr_cull_workspace_bytes(uint64_t instance_count, uint32_t mesh_count) { return vkr_cull_workspace_size(instance_count, mesh_count); }
-
 int32_t vkr_prep_indirect_noalloc(vkr_context* ctx, const vkr_cull_args* args) {
   if (!ctx || !args) return fail(VKR_ERR_INVALID_ARGUMENT, "vkr_prep_indirect_noalloc: null argument");
   if (args->instance_count > VKR_NOALLOC_MAX_INSTANCES)
-    return fail(VKR_ERR_INVALID_ARGUMENT, "vkr_prep_indirect_noalloc: %llu instances exceed the limit of %llu (use vkr_prep_indirect with a workspace)",
+    return fail(VKR_ERR_INVALID_ARGUMENT, "vkr_prep_indirect_noalloc: %llu instances exceed the limit of %llu (use vkr_prep_indirect)",
                 (unsigned long long)args->instance_count, (unsigned long long)VKR_NOALLOC_MAX_INSTANCES);
-  if (args->mesh_count > VKR_NOALLOC_MAX_MESHES)
-    return fail(VKR_ERR_INVALID_ARGUMENT, "vkr_prep_indirect_noalloc: %u meshes exceed the limit of %u (use vkr_prep_indirect with a workspace)",
-                args->mesh_count, (unsigned)VKR_NOALLOC_MAX_MESHES);
-  uint64_t ws_bytes = 0;
-  void* ws = vkr_cull_static_workspace(ctx->device, &ws_bytes);
-  if (!ws) return fail(VKR_ERR_BAD_STATE, "vkr_prep_indirect_noalloc: static workspace of device %d was not resolved at context creation", ctx->device);
-  return run_cull(ctx, args, ws, ws_bytes);
+  return run_cull(ctx, args, true);
 }
 
 int32_t vkr_kernel_get(vkr_context* ctx, const char* name, vkr_kernel** out_kernel) {

@@ -19,6 +19,11 @@ struct vkr_context {
   uint32_t tile_epoch = 0;           // tiled launches made so far
   TiledLayout last_tiled{};          // layout, extent and light count of the most recent one (vkr_deferred_tile_stats)
   uint32_t last_width = 0, last_height = 0, last_lights = 0;
+  // Single-launch cull: ticket counters + status words (vkr_cull_onepass_bytes), zeroed when (re)allocated and
+  // when the sequence number wraps.
+  void* cull_state = nullptr;
+  size_t cull_state_bytes = 0;
+  uint32_t cull_seq = 0;
 };
 
 // Records the message returned by vkr_last_error() for the calling thread and returns `code`.

@@ -86,7 +86,6 @@ struct CullParams {
   DrawCmd* cmd_out;
   uint32_t* visible;
   uint32_t* error_flag;  // may be null
-  void* workspace;       // deterministic mode
   uint32_t instance_count;
   uint32_t mesh_count;
   uint32_t first_mesh;
@@ -94,14 +93,25 @@ struct CullParams {
   float planes[24];
 };
 
-uint64_t vkr_cull_workspace_size(uint64_t instance_count, uint32_t mesh_count);
-// The deterministic mode's workspace as a per-GPU array inside the code object, for the entry point that
-// allocates nothing.  vkr_cull_static_init(device) resolves the array's address on `device`, which must be
-// the current device (once per device, at context creation: the first use of a code object on a device
-// may allocate); vkr_cull_static_workspace returns that address (null before init) and the array's size.
-constexpr uint64_t kCullStaticMaxInstances = 1ull << 22;
-constexpr uint32_t kCullStaticMaxMeshes = 1u << 16;
-hipError_t vkr_cull_static_init(int device);
-void* vkr_cull_static_workspace(int device, uint64_t* out_bytes);
+// Deterministic mode: its state is one 64-bit status word per 1024 instances, all zero before the first call.
+// seq: 1 .. kCullSeqEnd - 1, different from the seq of every earlier call on the same state since it was last
+// zeroed.  resident_blocks: how many workgroups of the kernel the device holds at once
+// (vkr_cull_blocks_per_cu() x CUs, or fewer); the grid never exceeds it.
+struct OnePassState {
+  uint64_t* status;
+  uint32_t seq;
+};
+constexpr uint32_t kCullSeqEnd = 1u << 30;
+uint64_t vkr_cull_state_bytes(uint64_t instance_count);
+uint32_t vkr_cull_blocks_per_cu();
 hipError_t vkr_launch_cull_atomic(const CullParams& p, hipStream_t stream);
-hipError_t vkr_launch_cull_deterministic(const CullParams& p, hipStream_t stream);
+hipError_t vkr_launch_cull_deterministic(const CullParams& p, void* state_mem, uint32_t seq, uint32_t resident_blocks, hipStream_t stream);
+
+// The same state as a per-GPU array inside the code object, for the entry point that allocates nothing.
+// vkr_cull_static_init(device) resolves the array's address on `device`, which must be the current device (once
+// per device, at context creation: the first use of a code object on a device may allocate).
+// vkr_cull_static_state returns that address (null before init), the array's size and the sequence number the
+// next call on that device must use; *out_clear_first: the numbers ran out, zero the array before the launch.
+constexpr uint64_t kCullStaticMaxInstances = 1ull << 22;
+hipError_t vkr_cull_static_init(int device);
+void* vkr_cull_static_state(int device, uint64_t* out_bytes, uint32_t* out_seq, bool* out_clear_first);
