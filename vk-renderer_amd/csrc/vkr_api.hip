@@ -389,6 +389,7 @@ int32_t vkr_context_create(int32_t device_ordinal, vkr_context** out_ctx) {
   // resolves the per-GPU address of the static cull workspace now, so that vkr_prep_indirect_noalloc never
   // triggers a first-use code object load (which allocates) on this device
   VKR_HIP(vkr_cull_static_init(device_ordinal));
+  (void)vkr_cull_blocks_per_cu();  // occupancy query of the deterministic cull, made here rather than inside a call
   VKR_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   *out_ctx = ctx.release();
   return VKR_OK;
