@@ -8,7 +8,7 @@
 //   Queue::oneTimeRecordSubmit/hasReadyBuffer  :124-168     Queue                      - HIP stream + events
 //   CommandBuffer (= vk::CommandBuffer)        :50-87       CommandBuffer              - records a vkr_cmd list
 //   Fence / Semaphore                          :27-48       Fence / Semaphore          - hipEvent / stream order
-//   Shader, ShaderIOBinding, loadShader   vkshader.hpp:9-37 Shader(stage, kernelName, ioBindings, pushSize)
+//   Shader, ShaderIOBinding, loadShader   vkshader.hpp:9-37 Shader(device, stage, loadShader(path) = kernel name, ioBindings, pushSize)
 //   PipelineLayout, DescriptorSetLayout, DedicatedDescriptorPool, DescriptorSet
 //                                    vkdescriptor.hpp:8-67  same names; bindings numbered per set in
 //                                                           declaration order (vkdescriptor.cpp:56-62)
@@ -23,7 +23,10 @@
 
 #include <array>
 #include <cstdint>
+#include <algorithm>
+#include <cstddef>
 #include <cstring>
+#include <filesystem>
 #include <functional>
 #include <initializer_list>
 #include <fstream>
@@ -43,28 +46,32 @@ inline void check(int32_t status, const char* what) {
 }
 
 // ---------------------------------------------------------------- small utilities (vkutils.hpp:15-54,161-174,229-233)
+// A non-owning view of consecutive elements, implicitly constructible from whatever a vw:: call site passes
+// where the reference takes a vw::ArrayProxy: one element, a C array, std::array, std::vector, a braced list, or
+// pointer + count.  Kept as a [first, last) range.
 template <typename T>
 class ArrayProxy {
  public:
   using value_type = T;
-  ArrayProxy() : mPtr{nullptr}, mCount{0} {}
-  ArrayProxy(const T& ref) : mPtr{&ref}, mCount{1} {}
+  ArrayProxy() = default;
+  ArrayProxy(const T& single) : mFirst{&single}, mLast{&single + 1} {}
   template <size_t N>
-  ArrayProxy(const T (&array)[N]) : mPtr{array}, mCount{static_cast<uint32_t>(N)} {}
+  ArrayProxy(const T (&items)[N]) : mFirst{items}, mLast{items + N} {}
   template <size_t N>
-  ArrayProxy(const std::array<T, N>& array) : mPtr{array.data()}, mCount{static_cast<uint32_t>(N)} {}
-  ArrayProxy(const std::vector<std::remove_const_t<T>>& v) : mPtr{v.data()}, mCount{static_cast<uint32_t>(v.size())} {}
-  ArrayProxy(const std::initializer_list<T>& l) : mPtr{l.begin()}, mCount{static_cast<uint32_t>(l.size())} {}
-  ArrayProxy(const T* ptr, uint32_t count) : mPtr{ptr}, mCount{count} {}
-  const T* data() const { return mPtr; }
-  const T& operator[](size_t i) const { return mPtr[i]; }
-  const T* begin() const { return mPtr; }
-  const T* end() const { return mPtr + mCount; }
-  uint32_t size() const { return mCount; }
+  ArrayProxy(const std::array<T, N>& items) : mFirst{items.data()}, mLast{items.data() + N} {}
+  ArrayProxy(const std::vector<std::remove_const_t<T>>& items) : mFirst{items.data()}, mLast{items.data() + items.size()} {}
+  ArrayProxy(const std::initializer_list<T>& items) : mFirst{items.begin()}, mLast{items.end()} {}
+  ArrayProxy(const T* items, uint32_t count) : mFirst{items}, mLast{items + count} {}
+  const T* begin() const { return mFirst; }
+  const T* end() const { return mLast; }
+  const T* data() const { return mFirst; }
+  uint32_t size() const { return static_cast<uint32_t>(mLast - mFirst); }
+  bool empty() const { return mFirst == mLast; }
+  const T& operator[](size_t i) const { return mFirst[i]; }
 
  private:
-  const T* mPtr;
-  uint32_t mCount;
+  const T* mFirst = nullptr;
+  const T* mLast = nullptr;
 };
 
 template <typename T>
@@ -75,10 +82,33 @@ template <typename T>
 inline uint64_t byteSize(const T& container) {
   return sizeof(typename T::value_type) * container.size();
 }
-inline void alignTo(uint64_t& size, uint64_t alignment) {
-  const uint64_t rem = size % alignment;
-  if (rem != 0) size += alignment - rem;
+inline void alignTo(uint64_t& size, uint64_t alignment) { size = (size + alignment - 1) / alignment * alignment; }
+
+// vw::loadShader (vkshader.hpp:18) returns the SPIR-V words of a file.  The kernels here are compiled into the
+// library and looked up by name, so what a call site gets back is that name, taken from the file name the
+// reference passes: "shaders/deferred.comp.spv" -> "deferred", "shaders/prep_indirect.comp.spv" -> "prep_indirect".
+// The file is not opened.
+inline std::string loadShader(const std::filesystem::path& path) {
+  const std::string file = path.filename().string();
+  const std::string name = file.substr(0, file.find('.'));
+  if (name.empty()) throw std::runtime_error("vkr::loadShader: '" + path.string() + "' names no kernel");
+  return name;
 }
+
+// vw::DataFile / vw::ImageFile (vkutils.hpp:192-206): a source of image bytes for StagingBuffer::queueImageCopy.
+class DataFile {
+ public:
+  virtual ~DataFile() = default;
+  virtual size_t dataSize() const = 0;
+  virtual void loadData(std::byte* dst) const = 0;
+};
+class Extent;
+enum class Format : uint32_t;
+class ImageFile : public DataFile {
+ public:
+  virtual Format getFormat() const;
+  virtual Extent getExtent() const = 0;
+};
 
 // ---------------------------------------------------------------- enums with the vk:: spellings the caller uses
 enum class Format : uint32_t {
@@ -93,7 +123,7 @@ enum class Format : uint32_t {
 enum class DescriptorType { eCombinedImageSampler, eUniformBuffer, eStorageBuffer, eStorageImage };
 enum class ShaderStageFlagBits { eCompute };
 enum class PipelineBindPoint { eCompute };
-enum class ImageLayout { eUndefined, eGeneral, eShaderReadOnlyOptimal, ePresentSrcKHR };
+enum class ImageLayout { eUndefined, eGeneral, eShaderReadOnlyOptimal, eTransferDstOptimal, ePresentSrcKHR };
 enum MemoryUsage { VKR_MEMORY_USAGE_GPU_ONLY = 0, VKR_MEMORY_USAGE_CPU_TO_GPU = 1 };
 using BufferUsageFlags = uint32_t;
 namespace BufferUse {
@@ -114,6 +144,7 @@ class Extent {
   Extent(uint32_t width, uint32_t height, uint32_t depth = 1) : width{width}, height{height}, depth{depth} {}
   uint32_t width, height, depth;
 };
+inline Format ImageFile::getFormat() const { return Format::eUndefined; }
 
 // ---------------------------------------------------------------- device / sync
 class Queue;
@@ -236,6 +267,7 @@ class Buffer {
 };
 
 class Image;
+class CommandBuffer;
 class ImageView {
  public:
   explicit ImageView(const Image* image) : mImage{image} {}
@@ -253,6 +285,16 @@ class Image {
         mStorage{allocator, uint64_t(mPitch) * extent.height, BufferUse::kStorageBuffer} {}
   static uint32_t rowPitch(Format f, uint32_t width) { return ((((width + 3u) / 4u) * 4u * texelBytes(f)) + 15u) & ~15u; }
   ImageView createView() const { return ImageView{this}; }
+  // vw::Image::transitionLayout (vkmemory.hpp:87-95), both forms, as main.cpp:221,227 call them inside the record
+  // lambda.  Linear images in HIP memory have no layouts and submissions of a Device are stream-ordered, so no
+  // barrier is recorded; what is kept is the check the validation layer would make: the command buffer must be
+  // recording and oldLayout must be eUndefined or the layout the image was last moved to.
+  static void transitionLayout(CommandBuffer& cmdBuffer, const Image& image, ImageLayout oldLayout, ImageLayout newLayout) {
+    image.transitionLayout(cmdBuffer, oldLayout, newLayout);
+  }
+  inline void transitionLayout(CommandBuffer& cmdBuffer, ImageLayout oldLayout, ImageLayout newLayout) const;
+  ImageLayout layout() const { return mLayout; }
+  void setLayoutAfterCopy(ImageLayout layout) const { mLayout = layout; }
   Format format() const { return mFormat; }
   Extent extent() const { return mExtent; }
   uint32_t pitch() const { return mPitch; }
@@ -282,6 +324,7 @@ class Image {
   Extent mExtent;
   uint32_t mPitch;
   Buffer mStorage;
+  mutable ImageLayout mLayout = ImageLayout::eUndefined;
 };
 
 class Sampler {};  // the deferred pass fetches texel centres with a nearest filter: nothing to configure
@@ -417,13 +460,14 @@ class DescriptorSetLayout {
 class PipelineLayout {
  public:
   PipelineLayout(ArrayProxy<std::reference_wrapper<Shader>> shaders) {
-    uint32_t setCount = 1;
-    for (auto& sh : shaders)
-      for (auto& b : sh.get().getIOBindings()) setCount = std::max(setCount, b.setIndex + 1);
-    std::vector<std::vector<DescriptorSetLayoutBinding>> perSet(setCount);
-    for (auto& sh : shaders) {
-      for (auto& b : sh.get().getIOBindings()) perSet[b.setIndex].push_back({static_cast<uint32_t>(perSet[b.setIndex].size()), b.type, b.count});
-      mPushSize += sh.get().getPushConstantSize();
+    std::vector<std::vector<DescriptorSetLayoutBinding>> perSet(1);
+    for (const Shader& shader : shaders) {
+      for (const ShaderIOBinding& io : shader.getIOBindings()) {
+        if (io.setIndex >= perSet.size()) perSet.resize(io.setIndex + 1);
+        auto& set = perSet[io.setIndex];
+        set.push_back({static_cast<uint32_t>(set.size()), io.type, io.count});  // next free binding number of that set
+      }
+      mPushSize += shader.getPushConstantSize();
     }
     for (auto& s : perSet) mLayouts.emplace_back(std::move(s));
   }
@@ -451,11 +495,10 @@ class ComputePipeline {
 // ---------------------------------------------------------------- command recording / submission
 class CommandBuffer {
  public:
-  enum class State { Initial, Recording, Executable, Pending, Invalid };
   explicit CommandBuffer(vkr_context* ctx) : mCtx{ctx} {}
   CommandBuffer(const CommandBuffer&) = delete;
   CommandBuffer& operator=(const CommandBuffer&) = delete;
-  CommandBuffer(CommandBuffer&& o) noexcept : mCtx{o.mCtx}, mCmd{o.mCmd}, mState{o.mState}, mFence{std::move(o.mFence)} { o.mCmd = nullptr; }
+  CommandBuffer(CommandBuffer&& o) noexcept : mCtx{o.mCtx}, mCmd{o.mCmd}, mRecording{o.mRecording}, mInFlight{std::move(o.mInFlight)} { o.mCmd = nullptr; }
   ~CommandBuffer() { vkr_cmd_destroy(mCmd); }
 
   template <typename T>
@@ -463,11 +506,17 @@ class CommandBuffer {
     vkr_cmd_destroy(mCmd);
     mCmd = nullptr;
     check(vkr_cmd_begin(mCtx, &mCmd), "CommandBuffer::begin");
-    mState = State::Recording;
-    recordFunc(*this);
+    mRecording = true;
+    try {
+      recordFunc(*this);
+    } catch (...) {
+      mRecording = false;
+      throw;
+    }
+    mRecording = false;
     check(vkr_cmd_end(mCmd), "CommandBuffer::end");
-    mState = State::Executable;
   }
+  bool recording() const { return mRecording; }
   void bindPipeline(PipelineBindPoint, const ComputePipeline& pipeline) { check(vkr_cmd_bind_kernel(mCmd, pipeline.kernel()), "bindPipeline"); }
   void pushConstants(const PipelineLayout&, ShaderStageFlagBits, uint32_t offset, uint32_t size, const void* values) {
     check(vkr_cmd_push_constants(mCmd, offset, size, values), "pushConstants");
@@ -499,27 +548,28 @@ class CommandBuffer {
   }
   void dispatch(uint32_t x, uint32_t y, uint32_t z) { check(vkr_cmd_dispatch(mCmd, x, y, z), "dispatch"); }
 
-  void onSubmit(std::shared_ptr<Fence> fence) {
-    mState = State::Pending;
-    mFence = std::move(fence);
-  }
-  bool isPending() {
-    if (mState != State::Pending) return false;
-    if (mFence->signaled()) {
-      mState = State::Invalid;
-      mFence.reset();
-      return false;
-    }
-    return true;
+  // The buffer may be recorded again once the fence of its last submission has signalled
+  // (the bookkeeping of vkcore.hpp:69-82).
+  void submittedWith(std::shared_ptr<Fence> fence) { mInFlight = std::move(fence); }
+  bool inFlight() {
+    if (mInFlight && mInFlight->signaled()) mInFlight.reset();
+    return mInFlight != nullptr;
   }
   vkr_cmd* getHandle() const { return mCmd; }
 
  private:
   vkr_context* mCtx;
   vkr_cmd* mCmd = nullptr;
-  State mState = State::Initial;
-  std::shared_ptr<Fence> mFence;
+  bool mRecording = false;
+  std::shared_ptr<Fence> mInFlight;
 };
+
+inline void Image::transitionLayout(CommandBuffer& cmdBuffer, ImageLayout oldLayout, ImageLayout newLayout) const {
+  if (!cmdBuffer.recording()) throw std::runtime_error("Image::transitionLayout: the command buffer is not recording");
+  if (oldLayout != ImageLayout::eUndefined && oldLayout != mLayout)
+    throw std::runtime_error("Image::transitionLayout: oldLayout is not the layout the image is in");
+  mLayout = newLayout;
+}
 
 class Queue {
  public:
@@ -527,29 +577,25 @@ class Queue {
   void allocateOneTimeBuffers(uint32_t count) {
     for (uint32_t i = 0; i < count; ++i) mBuffers.emplace_back(mCtx);
   }
-  bool hasReadyBuffer() {
-    for (auto& b : mBuffers)
-      if (!b.isPending()) return true;
-    return false;
-  }
+  bool hasReadyBuffer() { return idleBuffer() != mBuffers.end(); }
   template <typename T>
   std::shared_ptr<Fence> oneTimeRecordSubmit(T recordFunc, std::initializer_list<std::reference_wrapper<Semaphore>> = {}, std::initializer_list<uint32_t> = {},
                                              std::initializer_list<std::reference_wrapper<Semaphore>> = {}) {
-    CommandBuffer& cmd = getReadyOneTimeBuffer();
-    cmd.record(recordFunc);
+    const auto slot = idleBuffer();
+    if (slot == mBuffers.end())
+      throw std::runtime_error("Queue::oneTimeRecordSubmit: every one-time command buffer is still in flight (ask hasReadyBuffer() first)");
+    slot->record(recordFunc);
     vkr_fence* f = nullptr;
-    check(vkr_queue_submit(mCtx, cmd.getHandle(), &f), "Queue::submit");
+    check(vkr_queue_submit(mCtx, slot->getHandle(), &f), "Queue::submit");
     auto fence = std::make_shared<Fence>(f);
-    cmd.onSubmit(fence);
+    slot->submittedWith(fence);
     return fence;
   }
   void waitIdle() const { check(vkr_queue_wait_idle(mCtx), "Queue::waitIdle"); }
 
  private:
-  CommandBuffer& getReadyOneTimeBuffer() {
-    for (auto& b : mBuffers)
-      if (!b.isPending()) return b;
-    throw std::runtime_error("No recordable command buffers avaliable (hasReadyBuffer() not checked)");
+  std::vector<CommandBuffer>::iterator idleBuffer() {
+    return std::find_if(mBuffers.begin(), mBuffers.end(), [](CommandBuffer& b) { return !b.inFlight(); });
   }
   vkr_context* mCtx;
   std::vector<CommandBuffer> mBuffers;
@@ -564,34 +610,91 @@ inline Device::~Device() {
   vkr_context_destroy(mCtx);
 }
 
-// Bump-allocated pinned staging area with deferred copies (vkmemory.hpp:116-219).
+// Pinned staging area filled front to back, with the copies out of it deferred to flush()
+// (vw::StagingBuffer, vkmemory.hpp:116-219).
 class StagingBuffer : public Buffer {
  public:
   StagingBuffer(MemoryAllocator& allocator, uint64_t size, Queue& transferQueue)
       : Buffer{allocator, size, BufferUse::kStagingBuffer, VKR_MEMORY_USAGE_CPU_TO_GPU}, mQueue{transferQueue} {}
   template <typename T>
   void queueBufferCopy(const T& src, const Buffer& dst, uint64_t dstOffset = 0) {
-    const uint64_t n = byteSize(src);
-    if (n > mSegmentSizes[0]) throw std::runtime_error("Data size exceeds staging buffer size");
-    if (n > remainingSpace()) flush();
-    std::memcpy(mMappedPtr + mUsedBytes, src.data(), n);
-    mCopies.push_back({&dst, mUsedBytes, dstOffset, n});
-    mUsedBytes += n;
+    const uint64_t bytes = byteSize(src);
+    const uint64_t at = reserve(bytes, 1, "queueBufferCopy");
+    std::memcpy(mMappedPtr + at, src.data(), bytes);
+    mCopies.push_back({&dst, at, dstOffset, bytes});
   }
-  uint64_t remainingSpace() const { return mSegmentSizes[0] - mUsedBytes; }
+  // Several containers to consecutive destination offsets: one copy when they fit the staging area together,
+  // else one copy each.
+  template <typename T>
+  void queueBufferCopies(const T& srcs, const Buffer& dst, uint64_t baseDstOffset = 0) {
+    uint64_t total = 0;
+    for (const auto& src : srcs) total += byteSize(src);
+    if (total <= capacity()) {
+      uint64_t at = reserve(total, 1, "queueBufferCopies");
+      mCopies.push_back({&dst, at, baseDstOffset, total});
+      for (const auto& src : srcs) {
+        std::memcpy(mMappedPtr + at, src.data(), byteSize(src));
+        at += byteSize(src);
+      }
+    } else {
+      for (const auto& src : srcs) {
+        queueBufferCopy(src, dst, baseDstOffset);
+        baseDstOffset += byteSize(src);
+      }
+    }
+  }
+  // The file's tightly packed rows go into the staging area in the destination's row pitch, so that flush()
+  // moves the image with one copy.  The layouts are recorded on the image at flush(), as the reference's two
+  // transitions around its copy leave it in postLayout.
+  void queueImageCopy(const ImageFile& imageFile, const Image& dst, ImageLayout /*preLayout*/ = ImageLayout::eUndefined,
+                      ImageLayout postLayout = ImageLayout::eShaderReadOnlyOptimal) {
+    const Extent e = imageFile.getExtent();
+    if (e.width != dst.extent().width || e.height != dst.extent().height) throw std::runtime_error("StagingBuffer::queueImageCopy: extent differs from the image's");
+    const uint64_t row = uint64_t(e.width) * texelBytes(dst.format());
+    if (imageFile.dataSize() != row * e.height) throw std::runtime_error("StagingBuffer::queueImageCopy: data size does not match extent and format");
+    const uint64_t bytes = uint64_t(dst.pitch()) * e.height;
+    const uint64_t at = reserve(bytes, 16, "queueImageCopy");
+    if (row == dst.pitch()) {
+      imageFile.loadData(mMappedPtr + at);
+    } else {
+      std::vector<std::byte> tight(imageFile.dataSize());
+      imageFile.loadData(tight.data());
+      std::memset(mMappedPtr + at, 0, bytes);
+      for (uint32_t y = 0; y < e.height; ++y) std::memcpy(mMappedPtr + at + uint64_t(y) * dst.pitch(), tight.data() + uint64_t(y) * row, row);
+    }
+    mCopies.push_back({&dst.storage(), at, 0, bytes});
+    mImageLayouts.push_back({&dst, postLayout});
+  }
+  uint64_t remainingSpace() const { return capacity() - mUsedBytes; }
   void flush() {
     for (const auto& c : mCopies) check(vkr_buffer_upload(c.dst->getHandle(), c.dstOffset, mMappedPtr + c.srcOffset, c.bytes), "StagingBuffer::flush");
     mQueue.waitIdle();
+    for (const auto& [image, layout] : mImageLayouts) image->setLayoutAfterCopy(layout);
     mCopies.clear();
+    mImageLayouts.clear();
     mUsedBytes = 0;
   }
 
  private:
+  uint64_t capacity() const { return mSegmentSizes[0]; }
+  // Offset of `bytes` free bytes at the given alignment, flushing first when the tail is too short.
+  uint64_t reserve(uint64_t bytes, uint64_t alignment, const char* who) {
+    if (bytes > capacity()) throw std::runtime_error(std::string("StagingBuffer::") + who + ": " + std::to_string(bytes) + " bytes do not fit a staging area of " + std::to_string(capacity()));
+    uint64_t at = mUsedBytes;
+    alignTo(at, alignment);
+    if (at + bytes > capacity()) {
+      flush();
+      at = 0;
+    }
+    mUsedBytes = at + bytes;
+    return at;
+  }
   struct Copy {
     const Buffer* dst;
     uint64_t srcOffset, dstOffset, bytes;
   };
   std::vector<Copy> mCopies;
+  std::vector<std::pair<const Image*, ImageLayout>> mImageLayouts;
   uint64_t mUsedBytes = 0;
   Queue& mQueue;
 };

@@ -44,8 +44,8 @@ typedef enum vkr_status {
 typedef enum vkr_format {
   VKR_FORMAT_UNDEFINED = 0,
   VKR_FORMAT_R8G8B8A8_UNORM = 37,
-  VKR_FORMAT_B8G8R8A8_UNORM = 44, /* accepted for the output image; bytes are written in RGBA order, as the
-                                     reference's rgba8-declared store does into its BGRA swapchain image */
+  VKR_FORMAT_B8G8R8A8_UNORM = 44, /* output image only: the swapchain format the reference binds
+                                     (/root/reference/src/vkpresent.cpp:17); bytes in memory are B, G, R, A */
   VKR_FORMAT_R16G16B16A16_SFLOAT = 97,
   VKR_FORMAT_R32_SFLOAT = 100,
   VKR_FORMAT_R32G32B32A32_SFLOAT = 109,
@@ -129,7 +129,7 @@ typedef struct vkr_deferred_args {
   vkr_image2d material; /* R8G8B8A8_UNORM   (.g roughness, .b metalness) */
   vkr_image2d normal;   /* R16G16B16A16_SFLOAT (.rgb, un-normalised) */
   vkr_image2d depth;    /* D32_SFLOAT / R32_SFLOAT */
-  vkr_image2d out;      /* R8G8B8A8_UNORM (reference), or R16G16B16A16_SFLOAT / R32G32B32A32_SFLOAT
+  vkr_image2d out;      /* R8G8B8A8_UNORM / B8G8R8A8_UNORM (reference), or R16G16B16A16_SFLOAT / R32G32B32A32_SFLOAT
                            (pre-quantisation colour, alpha = 1) */
   const void* lights;   /* device: light_count records of VKR_LIGHT_STRIDE bytes */
   uint32_t light_count;

@@ -45,7 +45,7 @@ def run_deferred_gpu(vkr, ctx, case: dict, out_format: int, *, flags: int = 0, r
     args = vkr.make_deferred_args(gb, out, lights, lights_np.shape[0], case["push"], flags=flags, row0=r0, rows=nr)
     ctx.deferred_resolve(args)
     ctx.wait_idle()
-    if out_format == vkr.FORMAT_R8G8B8A8_UNORM:
+    if out_format in (vkr.FORMAT_R8G8B8A8_UNORM, vkr.FORMAT_B8G8R8A8_UNORM):
         arr = out.download(np.uint8, 4)
     elif out_format == vkr.FORMAT_R16G16B16A16_SFLOAT:
         arr = out.download(np.float16, 4)
@@ -56,3 +56,23 @@ def run_deferred_gpu(vkr, ctx, case: dict, out_format: int, *, flags: int = 0, r
 
 def sorted_segments(visible: np.ndarray, mesh_base: np.ndarray, counts: np.ndarray) -> list:
     return [np.sort(visible[int(b):int(b) + int(c)]) for b, c in zip(mesh_base, counts)]
+
+
+def image_row(img, y: int, dtype, channels: int) -> np.ndarray:
+    """Row y of a device image (one pitched row is downloaded, not the plane)."""
+    raw = img.buffer.download(np.uint8, img.pitch, offset=y * img.pitch)[: img.width * img.texel_bytes]
+    out = np.ascontiguousarray(raw).view(dtype)
+    return out.reshape(img.width, channels) if channels > 1 else out.reshape(img.width)
+
+
+def oracle_row(oracle, planes: dict, y: int, height: int, lights, push, *, radius_cutoff: bool = False, mode: str = "mix"):
+    """The oracle's 8-bit result and near-threshold mask for row y of a frame `height` rows tall, given only that
+    row's G-buffer texels (planes: 'albedo' (W,4) u8, 'material' (W,4) u8, 'normal' (W,4) f16, 'depth' (W,) f32).
+    The frame-sized arrays the oracle takes are zero-pitch views of the one row, so an 8K frame costs no memory."""
+    from numpy.lib.stride_tricks import as_strided
+    g = {}
+    for k, a in planes.items():
+        a = np.ascontiguousarray(a)
+        g[k] = as_strided(a, shape=(height,) + a.shape, strides=(0,) + a.strides, writeable=False)
+    res = oracle.deferred(g, lights, push, mode=mode, radius_cutoff=radius_cutoff, rows=(y, y + 1), want=("rgba8",))
+    return res["rgba8"][y], res["near_threshold"][y].astype(bool)

@@ -43,6 +43,19 @@ struct DeferredPushData {  // src/main.cpp:76-80
 };
 static_assert(sizeof(LightInfo) == 48 && sizeof(DeferredPushData) == 80);
 
+// vw::ImageFile over a file of tightly packed texels (stands in for the reference's stb / DDS loaders)
+class RawImageFile : public vkr::ImageFile {
+ public:
+  RawImageFile(const std::string& path, vkr::Extent extent) : mBytes{loadBinaryFile<uint8_t>(path)}, mExtent{extent} {}
+  size_t dataSize() const override { return mBytes.size(); }
+  void loadData(std::byte* dst) const override { std::memcpy(dst, mBytes.data(), mBytes.size()); }
+  vkr::Extent getExtent() const override { return mExtent; }
+
+ private:
+  std::vector<uint8_t> mBytes;
+  vkr::Extent mExtent;
+};
+
 struct CullPushData {
   float planes[24];
   uint32_t meshCount, firstMesh, firstInstance, flags;
@@ -65,9 +78,10 @@ int main(int argc, char** argv) {
     DeferredPushData deferredPush;
     std::memcpy(&deferredPush, pushWords.data(), sizeof(deferredPush));
 
+    // src/main.cpp:90: the path the reference loads its SPIR-V from names the kernel here
     vkr::Shader deferredCompShader{device,
                                    vkr::ShaderStageFlagBits::eCompute,
-                                   "deferred",
+                                   vkr::loadShader("shaders/deferred.comp.spv"),
                                    {{vkr::DescriptorType::eCombinedImageSampler, 4}, {vkr::DescriptorType::eUniformBuffer}, {vkr::DescriptorType::eStorageImage, 1, 1}},
                                    sizeof(DeferredPushData)};
 
@@ -77,11 +91,21 @@ int main(int argc, char** argv) {
     vkr::Image gSpecular{allocator, vkr::Format::eR8G8B8A8Unorm, windowExtent};
     vkr::Image gNormal{allocator, vkr::Format::eR16G16B16A16Sfloat, windowExtent};
     vkr::Image depthAttachment{allocator, vkr::Format::eD32Sfloat, windowExtent};
-    // the G-buffer fill is a raster pass in the reference; here the planes come from files
-    gAlbedo.upload(loadBinaryFile<uint8_t>(dir + "albedo.bin").data());
-    gSpecular.upload(loadBinaryFile<uint8_t>(dir + "material.bin").data());
-    gNormal.upload(loadBinaryFile<uint8_t>(dir + "normal.bin").data());
-    depthAttachment.upload(loadBinaryFile<uint8_t>(dir + "depth.bin").data());
+    // the G-buffer fill is a raster pass in the reference; here the planes come from files, staged the way the
+    // reference stages its textures (vw::StagingBuffer::queueImageCopy + flush, src/vkmodel.cpp / src/main.cpp:102-107);
+    // the staging area is smaller than the four planes together, so it flushes by itself on the way
+    {
+      const uint64_t px = uint64_t(windowExtent.width) * windowExtent.height;
+      vkr::StagingBuffer gbufferStaging{allocator, px * 8 + px * 4 + 4096, queue};
+      RawImageFile albedoFile{dir + "albedo.bin", windowExtent}, materialFile{dir + "material.bin", windowExtent};
+      RawImageFile normalFile{dir + "normal.bin", windowExtent}, depthFile{dir + "depth.bin", windowExtent};
+      gbufferStaging.queueImageCopy(albedoFile, gAlbedo);
+      gbufferStaging.queueImageCopy(materialFile, gSpecular);
+      gbufferStaging.queueImageCopy(normalFile, gNormal);
+      gbufferStaging.queueImageCopy(depthFile, depthAttachment);
+      gbufferStaging.flush();
+      if (gNormal.layout() != vkr::ImageLayout::eShaderReadOnlyOptimal) throw std::runtime_error("queueImageCopy did not leave the image in its post layout");
+    }
 
     auto gAlbedoView = gAlbedo.createView();
     auto gNormalView = gNormal.createView();
@@ -126,11 +150,16 @@ int main(int argc, char** argv) {
         continue;
       }
       const uint32_t imageIndex = submitted % swapImageCount;
+      // src/main.cpp:221-227, the compute half of the record lambda, with vw:: -> vkr:: and swapchain.getImage(i) ->
+      // swapImages[i]; lines :214-219 before it are the raster pass
       queue.oneTimeRecordSubmit([&](vkr::CommandBuffer& commandBuffer) {
+        vkr::Image::transitionLayout(commandBuffer, swapImages[imageIndex], vkr::ImageLayout::eUndefined, vkr::ImageLayout::eGeneral);
         commandBuffer.bindPipeline(vkr::PipelineBindPoint::eCompute, deferredComputePipeline);
         commandBuffer.pushConstants(deferredCompPipelineLayout, vkr::ShaderStageFlagBits::eCompute, 0, sizeof(deferredPush), &deferredPush);
-        commandBuffer.bindDescriptorSets(vkr::PipelineBindPoint::eCompute, deferredCompPipelineLayout, 0, {deferredDescriptorSet, swapImageDescriptorSets[imageIndex]}, {});
+        commandBuffer.bindDescriptorSets(vkr::PipelineBindPoint::eCompute, deferredCompPipelineLayout, 0,
+                                         {deferredDescriptorSet, swapImageDescriptorSets[imageIndex]}, {});
         commandBuffer.dispatch(windowExtent.width, windowExtent.height, 1);
+        vkr::Image::transitionLayout(commandBuffer, swapImages[imageIndex], vkr::ImageLayout::eGeneral, vkr::ImageLayout::ePresentSrcKHR);
       });
       ++submitted;
     }
@@ -152,7 +181,7 @@ int main(int argc, char** argv) {
 
       vkr::Shader cullShader{device,
                              vkr::ShaderStageFlagBits::eCompute,
-                             "prep_indirect",
+                             vkr::loadShader("shaders/prep_indirect.comp.spv"),
                              {{vkr::DescriptorType::eStorageBuffer}, {vkr::DescriptorType::eStorageBuffer}, {vkr::DescriptorType::eStorageBuffer},
                               {vkr::DescriptorType::eStorageBuffer}, {vkr::DescriptorType::eStorageBuffer}, {vkr::DescriptorType::eStorageBuffer}},
                              sizeof(CullPushData)};
@@ -165,7 +194,11 @@ int main(int argc, char** argv) {
       vkr::StagingBuffer staging{allocator, 64u << 20, queue};
       staging.queueBufferCopy(aabbMin, ssbo, ssbo.getSegmentDesc(0).offset);
       staging.queueBufferCopy(aabbMax, ssbo, ssbo.getSegmentDesc(1).offset);
-      staging.queueBufferCopy(meshBase, ssbo, ssbo.getSegmentDesc(2).offset);
+      {  // the segment table in two pieces to consecutive offsets with one call (vw::StagingBuffer::queueBufferCopies)
+        const size_t half = meshBase.size() / 2;
+        std::vector<std::vector<uint32_t>> pieces{{meshBase.begin(), meshBase.begin() + half}, {meshBase.begin() + half, meshBase.end()}};
+        staging.queueBufferCopies(pieces, ssbo, ssbo.getSegmentDesc(2).offset);
+      }
       staging.queueBufferCopy(cmdTemplate, ssbo, ssbo.getSegmentDesc(3).offset);
       staging.flush();
 
@@ -193,6 +226,19 @@ int main(int argc, char** argv) {
       ssbo.download(visible.data(), vkr::byteSize(visible), ssbo.getSegmentDesc(5).offset);
       saveBinaryFile(dir + "cmds.bin", cmds);
       saveBinaryFile(dir + "visible.bin", visible);
+    }
+
+    // error paths of the layout bookkeeping: a transition from a layout the image is not in
+    {
+      bool layoutThrew = false;
+      try {
+        queue.oneTimeRecordSubmit([&](vkr::CommandBuffer& cb) {
+          vkr::Image::transitionLayout(cb, swapImages[0], vkr::ImageLayout::eShaderReadOnlyOptimal, vkr::ImageLayout::eGeneral);
+        });
+      } catch (const std::runtime_error&) {
+        layoutThrew = true;
+      }
+      if (!layoutThrew) throw std::runtime_error("a transition from the wrong layout was accepted");
     }
 
     // error path: unknown kernel -> std::runtime_error, like the reference's wrapper-level failures

@@ -299,6 +299,12 @@ def test_fscene_parser_matches_json(vkr, synth, oracle, frame_mod):
     got = frame_mod.fscene_point_lights(text)
     assert got.tobytes() == oracle.fscene_point_lights(text).tobytes() and got["pos"][0].tolist() == [10.0, -0.25, 3.0]
     assert frame_mod.fscene_point_lights("{}").shape == (0,)
+    # a numeric literal far longer than any fixed buffer (all the digits of a double, then padding zeros): Python's
+    # json and nlohmann::json both accept it
+    long_x = "0." + "3" * 120 + "0" * 200 + "e1"
+    text = '{"lights":[{"type":"point_light","pos":[' + long_x + ',2,3],"intensity":[1,2,3],"direction":[0,0,1],"opening_angle":90,"penumbra_angle":5}]}'
+    got = frame_mod.fscene_point_lights(text)
+    assert got.tobytes() == oracle.fscene_point_lights(text).tobytes() and got["pos"][0][0] == np.float32(float(long_x))
 
 
 def test_fscene_parser_errors(vkr, frame_mod):

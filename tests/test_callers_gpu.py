@@ -9,7 +9,7 @@ import importlib
 import numpy as np
 import pytest
 
-from _util import assert_color_close
+from _util import assert_color_close, image_row, oracle_row
 
 pytestmark = pytest.mark.gpu
 
@@ -241,7 +241,7 @@ def test_fill_then_resolve_matches_oracle(vkr, ctx, synth, oracle, frame_mod):
     assert lit.max() > 40 and lit.std() > 5  # the lights really light the scene
 
 
-def test_full_8k_tiled_equals_whole_table_loop(vkr, ctx, synth, frame_mod):
+def test_full_8k_tiled_equals_whole_table_loop(vkr, ctx, synth, oracle, frame_mod):
     """BASELINE size of the tiled configuration: 7680x4320, 4096 lights, radius cutoff, on the analytic scene.
     The tile-list result (coarse bins, per-tile lists, ambient-only tiles) must be the bytes of the same kernel
     looping over the whole table, for the whole frame and for a screen band of it."""
@@ -260,9 +260,26 @@ def test_full_8k_tiled_equals_whole_table_loop(vkr, ctx, synth, frame_mod):
     ctx.wait_idle()
     tiled, flat = out_t.download(np.uint8, 4), out_f.download(np.uint8, 4)
     assert np.array_equal(tiled, flat)
+    st = ctx.tile_stats()  # of the tile-list call (the whole-table call builds no lists)
+    assert st["tiles"] == 240 * 135 and st["dark_tiles"] + st["listed_tiles"] + st["overflow_tiles"] == st["tiles"]
+    assert st["overflow_tiles"] == 0 and 0 < st["listed_tiles"] < st["tiles"] and 0 < st["max_list"] <= st["list_cap"]
+    assert 0.1 < st["mean_lights_per_pixel"] < 50
     ambient = np.rint(np.float32(0.05) * gb.albedo.download(np.uint8, 4)[..., :3].astype(np.float32)).astype(np.uint8)
     lit = (tiled[..., :3] != ambient).any(-1)
     assert 0.005 < lit.mean() < 0.9  # some of the frame is within reach of a light, most of it is not
+    # rows of the frame against the oracle (binary64 lighting on the reference's binary32 positions, radius rule
+    # applied per pixel): the first, the last and the three with the most lit pixels
+    rows = sorted({0, h - 1} | set(np.argsort(lit.sum(1))[-3:].tolist()))
+    checked_lit = 0
+    for y in rows:
+        planes = {"albedo": image_row(gb.albedo, y, np.uint8, 4), "material": image_row(gb.material, y, np.uint8, 4),
+                  "normal": image_row(gb.normal, y, np.float16, 4), "depth": image_row(gb.depth, y, np.float32, 1)}
+        ref, near = oracle_row(oracle, planes, y, h, lights, push, radius_cutoff=True)
+        d = np.abs(tiled[y].astype(int) - ref.astype(int))
+        d[near] = 0
+        assert d.max() <= 1, f"row {y}: {int((d > 1).sum())} channels off by more than 1 LSB"
+        checked_lit += int(lit[y].sum())
+    assert checked_lit > 1000
     r0, r1 = 1000, 1700
     out_t.buffer.fill_u32(0)
     ctx.deferred_resolve(vkr.make_deferred_args(gb, out_t, lbuf, L, push, flags=vkr.DEFERRED_RADIUS_CUTOFF, row0=r0, rows=r1 - r0))
@@ -330,6 +347,45 @@ def test_camera_path_frame_sharding(vkr, ctx, synth, frame_mod):
     # full run: frame f sits in slot f % 3 -> slots hold 3, 4, 5; sharded run: its k-th frame sits in slot k % 3 -> 1, 3, 5
     assert np.array_equal(part[1], full[0]) and np.array_equal(part[2], full[2])
     assert not np.array_equal(part[0], full[0])
+
+
+def test_camera_path_frame_at_full_size(vkr, ctx, synth, oracle, frame_mod):
+    """The camera-path configuration at its real size: 2^22-instance cull, analytic 3840x2160 G-buffer fill and a
+    256-light resolve per frame, three in flight.  The last frame's command buffer equals the oracle cull under that
+    frame's planes byte for byte, and sampled rows of its image equal the oracle pipeline (oracle fill -> oracle
+    resolve) within 1 LSB."""
+    w, h, L, n, m = 3840, 2160, 256, 1 << 22, 1024
+    spheres = synth.make_spheres(64)
+    lights = np.ascontiguousarray(synth.deferred_case(64, 36, L, config_index=5)["lights"], np.float32).reshape(-1, 12)
+    scene = synth.cull_case(n, m, config_index=2)
+    cs = vkr.CullScene(ctx, scene["aabb_min"], scene["aabb_max"], scene["mesh_base"], scene["cmd_template"])
+    loop = frame_mod.FrameLoop(ctx, w, h, lights, spheres, cs, frames_in_flight=3, cull_flags=vkr.CULL_DETERMINISTIC)
+    cam = frame_mod.Camera()
+    frames = 5
+    for f in range(frames):
+        last = frame_mod.Camera()
+        C.memmove(C.byref(last.c), C.byref(cam.c), C.sizeof(cam.c))
+        slot = loop.submit(cam)
+        cam.step_path()
+    ctx.wait_idle()
+    fc = frame_mod.frame_setup(last, frame_mod.reference_projection(w, h))
+    ref_c = oracle.cull(scene["aabb_min"], scene["aabb_max"], fc["planes"], scene["mesh_base"], scene["cmd_template"])
+    res = cs.results()
+    assert res["error"] == 0 and res["cmds"].tobytes() == ref_c["cmds"].tobytes()
+    written = np.zeros(n, bool)  # slots past a mesh's count are never written (earlier frames left their own there)
+    for b, c in zip(scene["mesh_base"], ref_c["cmds"]["instanceCount"]):
+        written[int(b):int(b) + int(c)] = True
+    assert np.array_equal(res["visible"][written], ref_c["visible"][written])
+    assert 0.02 < ref_c["mask"].mean() < 0.6
+    sc = frame_mod.make_gbuffer_scene(fc["view_proj"], fc["inv_view_proj"], last.pos, 64)
+    got = loop.outputs[slot].download(np.uint8, 4)
+    for y in (0, 700, 1080, 1500, h - 1):
+        g = oracle.gbuffer_fill(bytes(sc), spheres, w, h, rows=(y, y + 1))
+        planes = {k: g[k][0] for k in ("albedo", "material", "normal", "depth")}
+        ref, near = oracle_row(oracle, planes, y, h, lights, fc["deferred_push"])
+        d = np.abs(got[y].astype(int) - ref.astype(int))
+        d[near] = 0
+        assert d.max() <= 1, f"row {y}: {int((d > 1).sum())} channels off by more than 1 LSB"
 
 
 # ------------------------------------------------------------------------------------------ committed fixtures

@@ -22,25 +22,35 @@ def _oracles(oracle, case, radius=False, rows=None):
     return o32, omx
 
 
-def _check_float(got, o32, omx, what, rows=None):
+def _well_conditioned(o32, omx, sl, lights, what):
+    """Pixels where the binary32 GLSL-order evaluation is itself within 2e-5 of the binary64 one, i.e. where it can
+    serve as a reference at 1e-4.  The share of such pixels falls with the number of lights (each is a chance of a
+    light a fraction of a unit from a far surface, or of a mirror peak at the alpha floor).  Measured over the cases
+    of this file: 0.9996-1 at up to 13 lights, 0.998-0.999 at 32-64, 0.984-0.994 at 256, 0.975 at 1500; the floors
+    below sit within 1 % of those, so a change that makes the GPU comparison skip more pixels fails here."""
+    well = rel_err(o32["f32"][sl][..., :3], omx["f64"][sl][..., :3]).max(-1) <= 2e-5
+    floor = 0.985 if lights <= 64 else (0.974 if lights <= 256 else 0.965)
+    assert well.mean() >= floor, f"{what}: only {well.mean():.4f} of the pixels have a usable binary32 oracle value (floor {floor})"
+    return well
+
+
+def _check_float(got, o32, omx, what, lights, rows=None):
     sl = slice(None) if rows is None else slice(rows[0], rows[1])
     g = got[sl][..., :3]
     near = omx["near_threshold"][sl]
     assert near.mean() < 1e-3
     assert_color_close(g, omx["f64"][sl][..., :3], near, what + " vs mix oracle")
-    well = rel_err(o32["f32"][sl][..., :3], omx["f64"][sl][..., :3]).max(-1) <= 2e-5
-    assert well.mean() > 0.9
+    well = _well_conditioned(o32, omx, sl, lights, what)
     assert_color_close(g, o32["f32"][sl][..., :3], near | ~well, what + " vs f32 oracle")
     assert np.all(got[sl][..., 3] == 1.0)
 
 
-def _check_u8(got, o32, omx, what, rows=None):
+def _check_u8(got, o32, omx, what, lights, rows=None):
     sl = slice(None) if rows is None else slice(rows[0], rows[1])
     near = omx["near_threshold"][sl].astype(bool)
     # the binary32 GLSL-order evaluation is compared where it is itself well-conditioned (see _check_float): a light a
     # fraction of a unit from a far surface moves its own 8-bit result by more than one step
-    well = rel_err(o32["f32"][sl][..., :3], omx["f64"][sl][..., :3]).max(-1) <= 2e-5
-    assert well.mean() > 0.9
+    well = _well_conditioned(o32, omx, sl, lights, what)
     for name, ref, skip in (("mix", omx["rgba8"], near), ("f32", o32["rgba8"], near | ~well)):
         d = np.abs(got[sl].astype(np.int32) - ref[sl].astype(np.int32))
         d[skip] = 0
@@ -54,7 +64,7 @@ def test_float_parity(vkr, synth, oracle, ctx, w, h, lights):
     case = synth.deferred_case(w, h, lights, config_index=7)
     o32, omx = _oracles(oracle, case)
     got, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT)
-    _check_float(got, o32, omx, f"{w}x{h} L={lights}")
+    _check_float(got, o32, omx, f"{w}x{h} L={lights}", lights)
 
 
 @pytest.mark.parametrize("w,h,lights", [(64, 36, 13), (37, 19, 32), (128, 72, 256)])
@@ -62,7 +72,7 @@ def test_rgba8_parity(vkr, synth, oracle, ctx, w, h, lights):
     case = synth.deferred_case(w, h, lights, config_index=3)
     o32, omx = _oracles(oracle, case)
     got, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R8G8B8A8_UNORM)
-    _check_u8(got, o32, omx, f"{w}x{h} L={lights}")
+    _check_u8(got, o32, omx, f"{w}x{h} L={lights}", lights)
 
 
 def test_reference_sized_frame_1080p_32_lights(vkr, synth, oracle, ctx):
@@ -71,9 +81,9 @@ def test_reference_sized_frame_1080p_32_lights(vkr, synth, oracle, ctx):
     case = synth.deferred_case(1920, 1080, 32, config_index=0)
     o32, omx = _oracles(oracle, case)
     got, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT)
-    _check_float(got, o32, omx, "1920x1080 L=32")
+    _check_float(got, o32, omx, "1920x1080 L=32", 32)
     got8, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R8G8B8A8_UNORM)
-    _check_u8(got8, o32, omx, "1920x1080 L=32")
+    _check_u8(got8, o32, omx, "1920x1080 L=32", 32)
 
 
 def test_rgba16f_output(vkr, synth, oracle, ctx):
@@ -84,6 +94,19 @@ def test_rgba16f_output(vkr, synth, oracle, ctx):
     # one half-precision ulp (the float result may sit on either side of a rounding boundary)
     assert np.all(np.abs(got[..., :3].astype(np.float64) - ref.astype(np.float64)) <= np.spacing(np.abs(ref)).astype(np.float64))
     assert np.all(got[..., 3] == np.float16(1.0))
+
+
+def test_bgra8_output_is_the_rgba8_output_with_red_and_blue_swapped(vkr, synth, ctx):
+    """B8G8R8A8_UNORM is the format of the images the reference binds as outTex (its swapchain images,
+    /root/reference/src/vkpresent.cpp:17): byte 0 of a texel holds blue.  Whole-table and tile-list paths."""
+    case = synth.deferred_case(130, 70, 40, config_index=2)
+    case["push"] = case["push"].copy()
+    case["push"][3] = 60.0
+    for flags in (0, vkr.DEFERRED_RADIUS_CUTOFF):
+        rgba, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R8G8B8A8_UNORM, flags=flags)
+        bgra, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_B8G8R8A8_UNORM, flags=flags)
+        assert len(np.unique(rgba[..., 0].astype(int) - rgba[..., 2])) > 1  # red and blue do differ in this frame
+        assert np.array_equal(bgra[..., [2, 1, 0, 3]], rgba)
 
 
 def test_device_self_test(ctx):
@@ -121,7 +144,7 @@ def test_radius_cutoff_extension(vkr, synth, oracle, ctx, w, h, lights, radius):
     case["push"][3] = radius
     o32, omx = _oracles(oracle, case, radius=True)
     got, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT, flags=vkr.DEFERRED_RADIUS_CUTOFF)
-    _check_float(got, o32, omx, "radius cutoff")
+    _check_float(got, o32, omx, "radius cutoff", lights)
     flat, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT,
                                flags=vkr.DEFERRED_RADIUS_CUTOFF | vkr.DEFERRED_NO_TILE_LISTS)
     assert np.array_equal(got, flat)
@@ -189,7 +212,7 @@ def test_full_4k_properties(vkr, synth, oracle, ctx):
     assert np.isfinite(got).all()
     for rows in ((0, 2), (1079, 1081), (2158, 2160)):
         o32, omx = _oracles(oracle, case, rows=rows)
-        _check_float(got, o32, omx, f"4K rows {rows}", rows=rows)
+        _check_float(got, o32, omx, f"4K rows {rows}", 256, rows=rows)
     amb = 0.05 * case["gbuf"]["albedo"][..., :3].astype(np.float64) / 255.0
     # linearity: doubling every light colour doubles (colour - ambient)
     c2 = dict(case)

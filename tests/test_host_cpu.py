@@ -257,7 +257,7 @@ def test_resolve_kernels_use_no_scratch_memory():
         assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0, (name, k)
         assert k["vgpr_count"] <= (168 if tile else 128), (name, k)
         checked += 1
-    assert checked == 6
+    assert checked == 8
 
 
 @pytest.mark.parametrize("unit", ["cull", "scene", "gbuffer"])

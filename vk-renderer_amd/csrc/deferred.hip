@@ -302,6 +302,15 @@ __device__ __forceinline__ uint32_t quantize_unorm8(float c) {
   return (uint32_t)__builtin_rintf(t * 255.0f);
 }
 
+// One 8-bit texel, alpha 255: bytes R,G,B,A in memory for R8G8B8A8_UNORM, B,G,R,A for B8G8R8A8_UNORM (the
+// reference's swapchain format, /root/reference/src/vkpresent.cpp:17: a store through a view of that format puts
+// the colour's blue channel in byte 0).
+template <int kOutMode>
+__device__ __forceinline__ uint32_t pack_unorm8(const float (&rgb)[3]) {
+  const uint32_t r = quantize_unorm8(rgb[0]), g = quantize_unorm8(rgb[1]), b = quantize_unorm8(rgb[2]);
+  return kOutMode == kOutBgra8 ? (b | (g << 8) | (r << 16) | 0xFF000000u) : (r | (g << 8) | (b << 16) | 0xFF000000u);
+}
+
 // Shading cost class of a tile by the length of its list; the shading launch takes the classes from the top down.
 __device__ __forceinline__ uint32_t list_class(uint32_t count) { return count < 8u ? 0u : count < 32u ? 1u : count < 128u ? 2u : 3u; }
 static_assert(kListClasses == 4, "list_class() has four classes");
@@ -366,6 +375,7 @@ template <int kOutMode, bool kRadius, bool kList>
 __global__ __launch_bounds__(256, kList ? 3 : 4) void deferred_kernel(const DeferredParams p) {
   __shared__ float4 s_light[2 * kChunk + 4];  // +1 pair: the prefetch of the last iteration reads past the list
   __shared__ uint32_t s_stash[14][256];  // rows: see kRow* below
+  constexpr bool kIs8Bit = kOutMode == kOutRgba8 || kOutMode == kOutBgra8;
   const uint32_t t = threadIdx.x;
   const float4* __restrict__ lights = reinterpret_cast<const float4*>(p.lights);
   const uint32_t L = p.light_count;
@@ -472,8 +482,8 @@ __global__ __launch_bounds__(256, kList ? 3 : 4) void deferred_kernel(const Defe
   // results: the first pair's go to LDS (over the rows of the words just consumed) until the second
   // pair is done, so that each lane writes its four pixels with full-width stores
   auto keep_result = [&](int g, int i, const float (&rgb)[3]) {
-    if (kOutMode == kOutRgba8) {
-      s_stash[kRowAlbedo + g + i][t] = quantize_unorm8(rgb[0]) | (quantize_unorm8(rgb[1]) << 8) | (quantize_unorm8(rgb[2]) << 16) | 0xFF000000u;
+    if (kIs8Bit) {
+      s_stash[kRowAlbedo + g + i][t] = pack_unorm8<kOutMode>(rgb);
     } else if (g == 0) {
       s_stash[kRowAlbedo + i][t] = __float_as_uint(rgb[0]);
       s_stash[kRowMaterial + i][t] = __float_as_uint(rgb[1]);
@@ -551,7 +561,7 @@ __global__ __launch_bounds__(256, kList ? 3 : 4) void deferred_kernel(const Defe
   if (inside) {
     const uint32_t valid = min(4u, p.width - x0);
     uint8_t* orow = p.out + (size_t)y * p.pitch_out;
-    if (kOutMode == kOutRgba8) {
+    if (kIs8Bit) {
       uint32_t packed[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) packed[i] = s_stash[kRowAlbedo + i][t];
@@ -764,11 +774,10 @@ __global__ __launch_bounds__(256) void tile_lists_kernel(const DeferredParams p,
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int ch = 0; ch < 3; ++ch) rgb[i][ch] = kAmbient * unorm8(words[i], ch);
-        if (kOutMode == kOutRgba8) {
+        if (kOutMode == kOutRgba8 || kOutMode == kOutBgra8) {
           uint32_t packed[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            packed[i] = quantize_unorm8(rgb[i][0]) | (quantize_unorm8(rgb[i][1]) << 8) | (quantize_unorm8(rgb[i][2]) << 16) | 0xFF000000u;
+          for (int i = 0; i < 4; ++i) packed[i] = pack_unorm8<kOutMode>(rgb[i]);
           store_rgba8x4(orow, x0, valid, packed);
         } else {
           store_float4x4<kOutMode>(orow, x0, valid, rgb);
@@ -1018,6 +1027,7 @@ hipError_t vkr_launch_deferred(const DeferredParams& params, void* tiled_ws, uin
   }
   switch (p.out_mode) {
     case kOutRgba8: return launch_mode<kOutRgba8>(p, use_lists ? &lists : nullptr, cu_count, stream);
+    case kOutBgra8: return launch_mode<kOutBgra8>(p, use_lists ? &lists : nullptr, cu_count, stream);
     case kOutRgba16f: return launch_mode<kOutRgba16f>(p, use_lists ? &lists : nullptr, cu_count, stream);
     case kOutRgba32f: return launch_mode<kOutRgba32f>(p, use_lists ? &lists : nullptr, cu_count, stream);
     default: return hipErrorInvalidValue;

@@ -1,6 +1,7 @@
 // C ABI over HIP: contexts, buffers, the typed entry points and the command-list dispatch surface
-// declared in include/vkr_c.h.  No exception leaves this file; every failure sets the calling
-// thread's error string and returns a vkr_status.
+// declared in include/vkr_c.h.  No exception leaves this file (the two places that can run out of host memory,
+// the dispatch snapshot list and the statistics download, catch it); every failure sets the calling thread's
+// error string, which lives in fixed storage, and returns a vkr_status.
 
 #include <hip/hip_runtime.h>
 
@@ -23,7 +24,7 @@
 
 namespace {
 
-thread_local std::string g_last_error;
+thread_local char g_last_error[512] = "";  // fixed storage: reporting a failure never allocates
 
 #define fail vkr_fail
 
@@ -179,6 +180,7 @@ int32_t run_deferred(vkr_context* ctx, const vkr_deferred_args* a) {
   switch (a->out.format) {
     case VKR_FORMAT_R16G16B16A16_SFLOAT: p.out_mode = kOutRgba16f; break;
     case VKR_FORMAT_R32G32B32A32_SFLOAT: p.out_mode = kOutRgba32f; break;
+    case VKR_FORMAT_B8G8R8A8_UNORM: p.out_mode = kOutBgra8; break;
     default: p.out_mode = kOutRgba8; break;
   }
   p.cam[0] = a->push[0];
@@ -358,18 +360,16 @@ int32_t replay(vkr_context* ctx, const Dispatch& d) {
 }  // namespace
 
 int32_t vkr_fail(int32_t code, const char* fmt, ...) {
-  char buf[512];
   va_list ap;
   va_start(ap, fmt);
-  vsnprintf(buf, sizeof(buf), fmt, ap);
+  vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
   va_end(ap);
-  g_last_error = buf;
   return code;
 }
 
 extern "C" {
 
-const char* vkr_last_error(void) { return g_last_error.c_str(); }
+const char* vkr_last_error(void) { return g_last_error; }
 
 int32_t vkr_context_create(int32_t device_ordinal, vkr_context** out_ctx) {
   if (!out_ctx) return fail(VKR_ERR_INVALID_ARGUMENT, "vkr_context_create: null out pointer");
@@ -648,7 +648,11 @@ int32_t vkr_cmd_dispatch(vkr_cmd* cmd, uint32_t x, uint32_t y, uint32_t z) {
   if (!cmd) return fail(VKR_ERR_INVALID_ARGUMENT, "null argument");
   if (cmd->ended) return fail(VKR_ERR_BAD_STATE, "command list already ended");
   if (!cmd->cur.kernel) return fail(VKR_ERR_BAD_STATE, "dispatch without a bound kernel");
-  cmd->dispatches.push_back(Dispatch{cmd->cur, x, y, z});
+  try {
+    cmd->dispatches.push_back(Dispatch{cmd->cur, x, y, z});
+  } catch (const std::bad_alloc&) {
+    return fail(VKR_ERR_OUT_OF_MEMORY, "vkr_cmd_dispatch: out of host memory");
+  }
   return VKR_OK;
 }
 

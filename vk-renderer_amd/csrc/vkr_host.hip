@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <string>
 #include <utility>
 #include <vector>
@@ -89,15 +90,15 @@ struct Json {
   bool number(double* out) {
     ws();
     if (p >= end) return fail("expected number");
-    char buf[64];
-    size_t n = 0;
+    // the whole run of number characters, however long (a double printed with all its digits plus padding zeros
+    // can exceed any fixed buffer), NUL-terminated for strtod
     const char* q = p;
-    while (q < end && n + 1 < sizeof(buf) && (std::strchr("+-.eE", *q) != nullptr || (*q >= '0' && *q <= '9'))) buf[n++] = *q++;
-    buf[n] = 0;
-    if (n == 0) return fail("expected number");
+    while (q < end && (std::strchr("+-.eE", *q) != nullptr || (*q >= '0' && *q <= '9'))) ++q;
+    if (q == p) return fail("expected number");
+    const std::string literal(p, q);
     char* stop = nullptr;
-    const double v = std::strtod(buf, &stop);
-    if (stop != buf + n) return fail("malformed number");
+    const double v = std::strtod(literal.c_str(), &stop);
+    if (stop != literal.c_str() + literal.size()) return fail("malformed number");
     p = q;
     *out = v;
     return true;
@@ -360,6 +361,7 @@ void vkr_pack_point_lights(uint32_t count, const float* pos3, const float* inten
 }
 
 int32_t vkr_fscene_point_lights(const char* json_text, uint64_t json_bytes, vkr_light_info* out, uint32_t capacity, uint32_t* out_count) {
+  try {
   if (!json_text || !out_count) return vkr_fail(VKR_ERR_INVALID_ARGUMENT, "vkr_fscene_point_lights: null argument");
   *out_count = 0;
   Json j{json_text, json_text + json_bytes, {}, json_text};
@@ -399,9 +401,15 @@ int32_t vkr_fscene_point_lights(const char* json_text, uint64_t json_bytes, vkr_
   *out_count = found;
   if (overflow) return vkr_fail(VKR_ERR_OUT_OF_MEMORY, "fscene: %u point lights, capacity %u", found, capacity);
   return VKR_OK;
+  } catch (const std::bad_alloc&) {
+    return vkr_fail(VKR_ERR_OUT_OF_MEMORY, "vkr_fscene_point_lights: out of host memory");
+  } catch (...) {
+    return vkr_fail(VKR_ERR_DEVICE, "vkr_fscene_point_lights: unexpected exception");
+  }
 }
 
 int32_t vkr_scene_count(const vkr_scene_desc* desc, vkr_scene_counts* out_counts) {
+  try {
   if (!out_counts) return vkr_fail(VKR_ERR_INVALID_ARGUMENT, "vkr_scene_count: null out pointer");
   if (int32_t rc = check_desc(desc)) return rc;
   vkr_scene_counts c{};
@@ -424,9 +432,15 @@ int32_t vkr_scene_count(const vkr_scene_desc* desc, vkr_scene_counts* out_counts
   c.total_indices = (uint32_t)indices;
   *out_counts = c;
   return VKR_OK;
+  } catch (const std::bad_alloc&) {
+    return vkr_fail(VKR_ERR_OUT_OF_MEMORY, "vkr_scene_count: out of host memory");
+  } catch (...) {
+    return vkr_fail(VKR_ERR_DEVICE, "vkr_scene_count: unexpected exception");
+  }
 }
 
 int32_t vkr_scene_build_tables(const vkr_scene_desc* desc, const vkr_scene_counts* counts, vkr_scene_tables* out) {
+  try {
   if (!counts || !out) return vkr_fail(VKR_ERR_INVALID_ARGUMENT, "vkr_scene_build_tables: null argument");
   vkr_scene_counts check;
   if (int32_t rc = vkr_scene_count(desc, &check)) return rc;
@@ -460,6 +474,11 @@ int32_t vkr_scene_build_tables(const vkr_scene_desc* desc, const vkr_scene_count
   if (out->mesh_base) out->mesh_base[k] = total_matrices;
   if (out->vertex_base) out->vertex_base[k] = total_vertices;
   return VKR_OK;
+  } catch (const std::bad_alloc&) {
+    return vkr_fail(VKR_ERR_OUT_OF_MEMORY, "vkr_scene_build_tables: out of host memory");
+  } catch (...) {
+    return vkr_fail(VKR_ERR_DEVICE, "vkr_scene_build_tables: unexpected exception");
+  }
 }
 
 }  // extern "C"

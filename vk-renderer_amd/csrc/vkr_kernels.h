@@ -5,7 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-enum : uint32_t { kOutRgba8 = 0, kOutRgba16f = 1, kOutRgba32f = 2 };
+enum : uint32_t { kOutRgba8 = 0, kOutRgba16f = 1, kOutRgba32f = 2, kOutBgra8 = 3 };
 
 // Kernel argument block of the deferred resolve (passed by value: lives in SGPRs / kernarg).
 struct DeferredParams {
