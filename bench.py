@@ -115,27 +115,45 @@ def bench_callers(ctx, vkr, synth, vdist, args, K, WU, rank, world, barrier, max
                                         "frac": flops / (ms * 1e-3) / VALU_FP32_PEAK, "traffic": pmc.get("gbuffer_fill_kernel"), "algorithmic_flops": flops,
                                         "algorithmic_bytes": byt, "hbm_frac": byt / (ms * 1e-3) / HBM_PEAK}}
 
-    # 8K x 4096 lights with the radius cutoff and tile light lists, on the analytic scene (coherent depth)
+    # Radius cutoff with light lists on the analytic scene (coherent depth): the 8K x 4096-light configuration and the
+    # two 4K ones.  L_eff = mean number of lights a pixel's loop walked, measured from the lists of the timed frame;
+    # frac = max(algorithmic bytes / t / HBM peak, flops(L_eff) / t / VALU peak).
+    tiled_kernels = ("light_bins_kernel", "tile_lists_kernel<0>", "deferred_kernel<0, true, true>")
+
+    def tiled_line(Wt, Ht, Lt, Rt, profiled=False):
+        gbt = gb if (Wt, Ht) == (W, H) else vkr.GBuffer(ctx, Wt, Ht)
+        camt = synth.reference_camera(Wt, Ht)
+        frame.gbuffer_fill(ctx, gbt, sbuf, frame.make_gbuffer_scene(camt["vp"], camt["inv_vp"], camt["pos"], 64))
+        caset = synth.deferred_case(64, 36, Lt, config_index=3)
+        pusht = caset["push"].copy()
+        pusht[3] = Rt
+        lightst = ctx.buffer_from(caset["lights"])
+        outt = ctx.image(vkr.FORMAT_R8G8B8A8_UNORM, Wt, Ht)
+        targs = vkr.make_deferred_args(gbt, outt, lightst, Lt, pusht, flags=vkr.DEFERRED_RADIUS_CUTOFF)
+        ms = timed(ctx, lambda: ctx.deferred_resolve(targs), K, WU)
+        st = ctx.tile_stats()
+        l_eff = st["mean_lights_per_pixel"]
+        byt = Wt * Ht * 24.0
+        flops = Wt * Ht * (150.0 + 117.0 * l_eff)
+        hbm_frac, valu_frac = byt / (ms * 1e-3) / HBM_PEAK, flops / (ms * 1e-3) / VALU_FP32_PEAK
+        line = {"value": Wt * Ht / (ms * 1e-3) / 1e9, "unit": "Gpixel/s", "ms_per_call": ms, "lights": Lt, "radius": Rt,
+                "workload": f"{Wt}x{Ht}, {Lt} lights, radius cutoff {Rt}, coarse bins + per-tile light lists, analytic G-buffer",
+                "L_eff": l_eff, "lists": {k: st[k] for k in ("tiles", "dark_tiles", "listed_tiles", "overflow_tiles", "max_list", "list_cap")},
+                "roofline": {"bound": "hbm" if hbm_frac >= valu_frac else "valu_fp32", "frac": max(hbm_frac, valu_frac), "hbm_frac": hbm_frac,
+                             "valu_frac": valu_frac, "algorithmic_bytes": byt, "algorithmic_flops": flops,
+                             "traffic": sum(pmc[k] for k in tiled_kernels) if profiled and all(k in pmc for k in tiled_kernels) else None},
+                "hbm_frac": hbm_frac, "algorithmic_bytes": byt}
+        return line, (gbt, outt, lightst, pusht)
+
+    if not args.tiled_8k_only:
+        out["tiled_resolve_4k_256"], _ = tiled_line(W, H, 256, 25.0)
+        out["tiled_resolve_4k_4096"], _ = tiled_line(W, H, 4096, 25.0)
     W8, H8, L8, R8 = 7680, 4320, 4096, 25.0
-    gb8 = vkr.GBuffer(ctx, W8, H8)
-    cam8 = synth.reference_camera(W8, H8)
-    frame.gbuffer_fill(ctx, gb8, sbuf, frame.make_gbuffer_scene(cam8["vp"], cam8["inv_vp"], cam8["pos"], 64))
-    case8 = synth.deferred_case(64, 36, L8, config_index=3)
-    push8 = case8["push"].copy()
-    push8[3] = R8
-    lights8 = ctx.buffer_from(case8["lights"])
-    out8 = ctx.image(vkr.FORMAT_R8G8B8A8_UNORM, W8, H8)
-    targs = vkr.make_deferred_args(gb8, out8, lights8, L8, push8, flags=vkr.DEFERRED_RADIUS_CUTOFF)
-    ms = timed(ctx, lambda: ctx.deferred_resolve(targs), K, WU)
-    out["tiled_resolve_8k"] = {"value": W8 * H8 / (ms * 1e-3) / 1e9, "unit": "Gpixel/s", "ms_per_call": ms, "lights": L8, "radius": R8,
-                               "workload": f"{W8}x{H8}, {L8} lights, radius cutoff {R8}, coarse bins + per-tile LDS light lists, analytic G-buffer",
-                               "hbm_frac": W8 * H8 * 24.0 / (ms * 1e-3) / HBM_PEAK, "algorithmic_bytes": W8 * H8 * 24.0,
-                               "traffic": pmc.get("deferred_kernel<0, true, true>")}
-    if world > 1:  # the same 8K frame in screen bands, one band per rank, gathered
-        tb = band_bench(gb8, out8, lights8, L8, push8, vkr.DEFERRED_RADIUS_CUTOFF, W8, H8)
-        out["tiled_resolve_8k"]["band_sharded"] = {"value": float(W8) * H8 * K / tb / 1e9, "unit": "Gpixel/s", "ms_per_frame": tb / K * 1e3,
-                                                   "scaling": "strong", "collective": "all_gather_into_tensor of rgba8 bands (RCCL)"}
+    out["tiled_resolve_8k"], (gb8, out8, lights8, push8) = tiled_line(W8, H8, L8, R8, profiled=True)
+    if world > 1:  # the same 8K frame in screen bands, one band per rank, gathered on rank 0
+        out["tiled_resolve_8k"]["band_sharded"] = band_bench(gb8, out8, lights8, L8, push8, vkr.DEFERRED_RADIUS_CUTOFF, W8, H8)
     del gb8, out8, lights8
+    # the fill above left the analytic scene in gb; the camera path below fills its own G-buffer
 
     # camera path: 64 frames, each = cull of the N-instance set + analytic fill + resolve with L lights
     scene = synth.cull_case(N, M, config_index=2 + 10 * rank)
@@ -172,6 +190,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cull", action="store_true")
     ap.add_argument("--no-cold", action="store_true", help="skip the run that rotates over four G-buffer sets")
+    ap.add_argument("--tiled-8k-only", action="store_true", help="skip the two 4K radius-cutoff lines (counter passes: keeps the list kernels' per-launch averages to one workload)")
     ap.add_argument("--no-callers", action="store_true", help="skip the steps either side of the passes (bounds, G-buffer producers, camera path)")
     args = ap.parse_args()
 
@@ -197,10 +216,15 @@ def main():
     torch.cuda.set_device(device_index)
     coll_device = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
+        # a rank that dies or hangs must end the run, not stall it: collectives time out (RCCL's watchdog aborts the
+        # communicator and raises in every surviving rank), and main() turns any exception into a non-zero exit
+        from datetime import timedelta
+        limit = timedelta(seconds=float(os.environ.get("VKR_BENCH_COLLECTIVE_TIMEOUT_S", "120")))
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index), timeout=limit)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=limit)
 
     def barrier():
         if world > 1:
@@ -298,39 +322,86 @@ def main():
         del sets[1:], cargs
 
     # ---------------------------------------------------------------- deferred: one frame in bands
+    # torch sees the library's stream as an external stream: a collective issued while it is current is ordered
+    # after the kernels already on it, and waiting for the collective's work handle makes the library's stream (not
+    # the host) wait for the collective.
+    lib_stream = torch.cuda.ExternalStream(ctx.stream(), device=torch.device("cuda", device_index))
+
+    def gather_to_rank0(send, recv_list):
+        """Asynchronous gather of equal-sized uint8 tensors to rank 0 (RCCL: grouped send/recv, one link per peer)."""
+        if backend == "nccl":
+            with torch.cuda.stream(lib_stream):
+                return dist.gather(send, recv_list if rank == 0 else None, dst=0, async_op=True)
+        ctx.wait_idle()  # rehearsal through host memory: the copy below is not ordered with the library's stream
+        host = send.cpu()
+        return dist.gather(host, recv_list if rank == 0 else None, dst=0, async_op=True)
+
+    def wait_work(work):
+        if work is None:
+            return
+        if backend == "nccl":
+            with torch.cuda.stream(lib_stream):
+                work.wait()  # stream-level: later kernels on the library's stream start after the gather
+        else:
+            work.wait()
+
     def band_bench(gbuf, out_img, lights_buf, n_lights, push, flags, width, height):
-        """Seconds for K steps of: this rank resolves its band of rows of ONE frame, then the bands are gathered."""
+        """This rank resolves its band of rows of ONE frame and the bands are gathered on rank 0, K times.  The band
+        tensors are double-buffered: the gather of frame k runs on RCCL's stream while frame k+1 is resolved, and a
+        buffer is written again only after its previous gather has finished.  Afterwards rank 0 checks the gathered
+        frame against its own resolve of the whole frame (outside the timed region)."""
         r0, r1 = vdist.band_rows(height, world, rank)
         rows_max = vdist.band_rows(height, world, 0)[1]
         pitch = out_img.pitch
-        band_t = torch.zeros(rows_max * pitch, dtype=torch.uint8, device="cuda")
-        full_t = torch.zeros(world * rows_max * pitch, dtype=torch.uint8, device=coll_device)
-        bargs = vkr.make_deferred_args(gbuf, out_img, lights_buf, n_lights, push, flags=flags, row0=r0, rows=r1 - r0)
-        bargs.out = vkr.Image2D(band_t.data_ptr(), width, r1 - r0, pitch, vkr.FORMAT_R8G8B8A8_UNORM)
+        bands = [torch.zeros(rows_max * pitch, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        recv = [[torch.zeros(rows_max * pitch, dtype=torch.uint8, device=coll_device) for _ in range(world)] if rank == 0 else None for _ in range(2)]
+        bargs = []
+        for t in bands:
+            a = vkr.make_deferred_args(gbuf, out_img, lights_buf, n_lights, push, flags=flags, row0=r0, rows=r1 - r0)
+            a.out = vkr.Image2D(t.data_ptr(), width, r1 - r0, pitch, vkr.FORMAT_R8G8B8A8_UNORM)
+            bargs.append(a)
+        works = [None, None]
 
-        def band_step():
-            ctx.deferred_resolve(bargs)
-            ctx.wait_idle()
-            dist.all_gather_into_tensor(full_t, band_t if backend == "nccl" else band_t.cpu())
+        def band_step(k):
+            b = k & 1
+            wait_work(works[b])  # the gather that last read this buffer
+            ctx.deferred_resolve(bargs[b])
+            works[b] = gather_to_rank0(bands[b], recv[b])
 
-        for _ in range(WU):
-            band_step()
+        for k in range(WU):
+            band_step(k)
+        for w_ in works:
+            wait_work(w_)
+        ctx.wait_idle()
         torch.cuda.synchronize()
         barrier()
         tb0 = time.perf_counter()
-        for _ in range(K):
-            band_step()
+        for k in range(K):
+            band_step(k)
+        for w_ in works:
+            wait_work(w_)
+        ctx.wait_idle()
         torch.cuda.synchronize()
         barrier()
-        return max_over_ranks(time.perf_counter() - tb0)
+        tb = max_over_ranks(time.perf_counter() - tb0)
+        verified = None
+        if rank == 0:
+            ctx.deferred_resolve(vkr.make_deferred_args(gbuf, out_img, lights_buf, n_lights, push, flags=flags))
+            ctx.wait_idle()
+            whole = out_img.download(np.uint8, 4)
+            last = recv[(K - 1) & 1]
+            got = np.concatenate([last[r].cpu().numpy().reshape(rows_max, pitch)[: vdist.band_rows(height, world, r)[1] - vdist.band_rows(height, world, r)[0], : width * 4]
+                                  for r in range(world)]).reshape(height, width, 4)
+            verified = bool(np.array_equal(got, whole))
+        return {"value": float(width) * height * K / tb / 1e9, "unit": "Gpixel/s", "ms_per_frame": tb / K * 1e3, "scaling": "strong",
+                "collective": "gather of rgba8 bands to rank 0 (RCCL), double-buffered: the gather of frame k overlaps the resolve of frame k+1",
+                "verified": verified}
 
     if world > 1:
         frame = synth.deferred_case(W, H, L, config_index=1)  # the same frame on every rank
         gb.upload(frame["gbuf"])
         lights.upload(frame["lights"])
-        tb = band_bench(gb, out, lights, L, frame["push"], 0, W, H)
-        result["band_sharded"] = {"value": float(W) * H * K / tb / 1e9, "unit": "Gpixel/s", "ms_per_frame": tb / K * 1e3,
-                                  "scaling": "strong", "collective": "all_gather_into_tensor of rgba8 bands (RCCL)"}
+        result["band_sharded"] = band_bench(gb, out, lights, L, frame["push"], 0, W, H)
 
     # ---------------------------------------------------------------- cull
     if not args.no_cull:
@@ -363,7 +434,7 @@ def main():
             call_ms = e1.elapsed_ms_since(e0) / K
             vis = int(css[0].results()["cmds"]["instanceCount"].sum())
             cb = cull_algorithmic(N, vis, M)
-            kernels = ("cull_init_cmds", "cull_atomic_kernel") if flags == 0 else ("cull_mask_kernel", "cull_place_kernel")
+            kernels = ("cull_init_cmds", "cull_atomic_kernel") if flags == 0 else ("cull_onepass_kernel",)
             c_traffic = sum(pmc[k] for k in kernels) if default_workload and all(k in pmc for k in kernels) else None
             cull[mode_name] = {"value": float(N) * K * world / cw / 1e9, "unit": "G instances/s", "ms_per_call": call_ms,
                                "visible_fraction": vis / N,
@@ -381,29 +452,49 @@ def main():
             part = vkr.CullScene(ctx, shared["aabb_min"][i0:i1], shared["aabb_max"][i0:i1], shared["mesh_base"][m0:m1] - np.uint32(i0),
                                  shared["cmd_template"][m0:m1], first_mesh=m0, first_instance=i0)
             cap = max(max(c[1] - c[0] for c in cuts) * 20, 16)
-            mine_t = torch.zeros(cap, dtype=torch.uint8, device="cuda")
-            all_t = torch.zeros(world * cap, dtype=torch.uint8, device=coll_device)
-            pargs = part.args(shared["planes"], 0)
-            pargs.cmd_out = mine_t.data_ptr()  # the commands of this rank's meshes land in the tensor that is gathered
+            mine = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in range(2)]
+            recv = [[torch.zeros(cap, dtype=torch.uint8, device=coll_device) for _ in range(world)] if rank == 0 else None for _ in range(2)]
+            pargs = []
+            for t in mine:
+                a = part.args(shared["planes"], 0)
+                a.cmd_out = t.data_ptr()  # the commands of this rank's meshes land in the tensor that is gathered
+                pargs.append(a)
+            works = [None, None]
 
-            def range_step():
-                ctx.prep_indirect(pargs)
-                ctx.wait_idle()
-                dist.all_gather_into_tensor(all_t, mine_t if backend == "nccl" else mine_t.cpu())
+            def range_step(k):
+                b = k & 1
+                wait_work(works[b])
+                ctx.prep_indirect(pargs[b])
+                works[b] = gather_to_rank0(mine[b], recv[b])
 
-            for _ in range(WU):
-                range_step()
+            for k in range(WU):
+                range_step(k)
+            for w_ in works:
+                wait_work(w_)
+            ctx.wait_idle()
             torch.cuda.synchronize()
             barrier()
             r0_ = time.perf_counter()
-            for _ in range(K):
-                range_step()
+            for k in range(K):
+                range_step(k)
+            for w_ in works:
+                wait_work(w_)
+            ctx.wait_idle()
             torch.cuda.synchronize()
             barrier()
             rt = max_over_ranks(time.perf_counter() - r0_)
+            verified = None
+            if rank == 0:  # the assembled command buffer against this rank's cull of the whole scene
+                whole = vkr.CullScene(ctx, shared["aabb_min"], shared["aabb_max"], shared["mesh_base"], shared["cmd_template"])
+                whole.run(shared["planes"], 0)
+                ctx.wait_idle()
+                last = recv[(K - 1) & 1]
+                got = b"".join(last[r].cpu().numpy()[: (cuts[r][1] - cuts[r][0]) * 20].tobytes() for r in range(world))
+                verified = got == whole.results()["cmds"].tobytes()
+                del whole
             cull["range_sharded"] = {"value": float(N) * K / rt / 1e9, "unit": "G instances/s", "ms_per_call": rt / K * 1e3, "scaling": "strong",
-                                     "collective": "all_gather_into_tensor of the per-mesh commands (RCCL)",
-                                     "ranges": [[int(c[2]), int(c[3])] for c in cuts]}
+                                     "collective": "gather of the per-mesh commands to rank 0 (RCCL), double-buffered",
+                                     "ranges": [[int(c[2]), int(c[3])] for c in cuts], "verified": verified}
         result["cull"] = cull
 
     # ---------------------------------------------------------------- callers either side of the passes
@@ -414,26 +505,49 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         import oracle  # checker/baseline only: never on the measured GPU path
         oracle.build()
-        cores = min(16, os.cpu_count() or 1)
-        rows = H  # the whole frame: about 70 core-seconds of the scalar restatement at 4K x 256
+        # Threads: every CPU this process may run on.  os.cpu_count() reports the whole machine; the scheduler
+        # affinity mask and the thread budget the box exports (OMP_NUM_THREADS) say what this job's share is.
+        host_cpus = os.cpu_count() or 1
+        share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else host_cpus
+        budget = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+        cores = max(1, min(share, budget) if budget > 0 else share)
+        # a bounded sample: about 20 s of CPU work (the scalar restatement shades ~0.18 Mpixel/s per core at 256 lights)
+        rows = int(min(H, max(cores, 20.0 * cores * 0.18e6 * (256.0 / max(L, 1)) / W)))
         tc0 = time.perf_counter()
         oracle.deferred(case["gbuf"], case["lights"], case["push"], mode="f32", rows=(0, rows), threads=cores, want=("rgba8",))
         tc = time.perf_counter() - tc0
         result["cpu_baseline"] = {"value": float(W) * rows / tc / 1e9, "unit": "Gpixel/s", "cores": cores, "kind": "port",
                                   "sample": f"rows 0..{rows} of the same {W}x{H} frame, {L} lights, binary32 C restatement of deferred.comp, {cores} threads",
-                                  "seconds": tc}
-        rows1 = max(H // 16, 1)  # one thread on a sixteenth of the frame: about as long as the 16-thread run
+                                  "seconds": tc, "host_cpus": host_cpus, "cpus_in_affinity_mask": share, "thread_budget_env": budget or None}
+        rows1 = max(rows // cores, 1)  # one thread on its share of those rows: about as long as the threaded run
         tc0 = time.perf_counter()
         oracle.deferred(case["gbuf"], case["lights"], case["push"], mode="f32", rows=(0, rows1), threads=1, want=("rgba8",))
         tc1 = time.perf_counter() - tc0
         result["cpu_baseline"]["one_core"] = {"value": float(W) * rows1 / tc1 / 1e9, "unit": "Gpixel/s", "sample": f"rows 0..{rows1}, 1 thread", "seconds": tc1}
         if not args.no_cull:
+            from concurrent.futures import ThreadPoolExecutor
             sc = scenes[0]
             tc0 = time.perf_counter()
             oracle.cull(sc["aabb_min"], sc["aabb_max"], planes, sc["mesh_base"], sc["cmd_template"], want_mask=False)
             tc = time.perf_counter() - tc0
             result["cull"]["cpu_baseline"] = {"value": float(N) / tc / 1e9, "unit": "G instances/s", "cores": 1, "kind": "port",
                                               "sample": f"all {N} instances, scalar C restatement", "seconds": tc}
+            # all cores: mesh ranges (the multi-GPU partition) culled side by side, the C code runs outside the interpreter lock
+            cuts = [c for c in vdist.mesh_range_cuts(sc["mesh_base"], N, cores) if c[1] > c[0]]
+
+            def cull_range(c):
+                m0, m1, i0, i1 = c
+                sub = sc["aabb_min"][i0:i1].copy()
+                sub[:, 3] = (sub[:, 3].view(np.uint32) - np.uint32(m0)).view(np.float32)
+                return oracle.cull(sub, sc["aabb_max"][i0:i1], planes, sc["mesh_base"][m0:m1] - np.uint32(i0), sc["cmd_template"][m0:m1], want_mask=False)
+
+            tc0 = time.perf_counter()
+            with ThreadPoolExecutor(cores) as ex:
+                parts = list(ex.map(cull_range, cuts))
+            tcm = time.perf_counter() - tc0
+            assert sum(int(p_["cmds"]["instanceCount"].sum()) for p_ in parts) == int(css[0].results()["cmds"]["instanceCount"].sum())
+            result["cull"]["cpu_baseline"]["all_cores"] = {"value": float(N) / tcm / 1e9, "unit": "G instances/s", "cores": cores,
+                                                           "sample": f"all {N} instances in {len(cuts)} mesh ranges, one thread each (includes slicing the inputs)", "seconds": tcm}
 
     if rank == 0:
         print(json.dumps(result))
@@ -442,4 +556,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as e:  # a failed collective, a HIP error, a dead peer: say so and leave with a non-zero status
+        import traceback
+        traceback.print_exc()
+        print(f"bench.py: rank {os.environ.get('RANK', '0')} failed: {e}", file=sys.stderr, flush=True)
+        os._exit(1)  # not sys.exit: a hung communicator's destructor must not get the chance to block the exit
