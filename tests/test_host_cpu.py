@@ -228,7 +228,7 @@ def test_cull_object_code_has_no_float_fma():
 
 
 def test_resolve_kernels_use_no_scratch_memory():
-    """The resolve variants that production paths launch (plain and tile-list, every output format) must keep all
+    """The resolve kernels that production paths launch (whole-table, list building and list shading, every output format) must keep all
     their state in registers and LDS: a spilled register is HBM traffic of the order of the output itself (an earlier
     build wrote 61 MB per 4K frame instead of 33 MB because of four spilled registers)."""
     obj = os.path.join(ROOT, "vk-renderer_amd", "lib", "deferred.o")
@@ -248,16 +248,14 @@ def test_resolve_kernels_use_no_scratch_memory():
         kernels[name] = {k: int(re.search(rf"\.{k}:\s+(\d+)", block).group(1)) for k in ("private_segment_fixed_size", "vgpr_spill_count", "vgpr_count")}
     checked = 0
     for name, k in kernels.items():
-        m = re.search(r"deferred_kernelILi(\d)ELb([01])ELb([01])E", name)
-        if not m:
-            continue
-        radius, tile = m.group(2) == "1", m.group(3) == "1"
-        if radius and not tile:
-            continue  # the whole-table loop with the cutoff is a diagnostic, not a production path
+        flat = re.search(r"deferred_kernelILi(\d)ELb([01])EE", name)
+        production = (flat and flat.group(2) == "0") or "deferred_list_kernel" in name or "tile_lists_kernel" in name or "light_bins_kernel" in name
+        if not production:
+            continue  # the whole-table loop with the per-pixel cutoff is a diagnostic, not a production path
         assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0, (name, k)
-        assert k["vgpr_count"] <= (168 if tile else 128), (name, k)
+        assert k["vgpr_count"] <= 128, (name, k)  # four waves per SIMD
         checked += 1
-    assert checked == 8
+    assert checked == 4 + 4 + 4 + 1  # four output formats each of: whole-table kernel, list shading, list building; the bins
 
 
 @pytest.mark.parametrize("unit", ["cull", "scene", "gbuffer"])
