@@ -22,14 +22,19 @@ src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0]
+def newest(pattern):
+    """gpurun merges every run's files into the same directory: take the most recent match."""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
+stats = newest(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
 shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 bench_line = [l for l in open(os.path.join(src, "bench_under_trace.log")) if l.startswith("{")]
 if bench_line:
     open(os.path.join(dst, f"{tag}_bench_under_trace.json"), "w").write(bench_line[-1])
 
 out = collections.defaultdict(dict)
-for f in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
+for f in [newest(os.path.join(d, "*", "*counter_collection.csv")) for d in glob.glob(os.path.join(src, "pmc_*")) if os.path.isdir(d)]:
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     dur = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):

@@ -98,8 +98,14 @@ constexpr int kInstBlock = 256;
 __global__ __launch_bounds__(kInstBlock) void instance_aabb_kernel(const float4* __restrict__ matrices, const uint32_t* __restrict__ mesh_base,
                                                                    const float4* __restrict__ mesh_aabb, uint32_t mesh_count, uint32_t instance_count,
                                                                    float4* __restrict__ aabb_min, float4* __restrict__ aabb_max) {
-  // one float4 of padding per 4 instances: the 16-byte column reads of 16 consecutive lanes then fall in distinct banks
-  __shared__ float4 s_mat[kInstBlock * 4 + kInstBlock / 4];
+  // Column-major staging: column c of instance i at s_mat[c * kColStride + i].  The reads (lane = instance) are then
+  // consecutive float4; the writes (lane k holds column k & 3 of instance k >> 2) put the 16 lanes that share an
+  // LDS pass at word 4*i + 16*c of the 64 banks, i, c = 0..3: distinct, thanks to the 4 float4 of padding per
+  // column.  SQ_LDS_BANK_CONFLICT still reads a third of SQ_LDS_IDX_ACTIVE for this kernel, exactly as it did for a
+  // row-major staging with other padding: the counter charges every 128-bit access of a 64-lane wave its extra
+  // passes (1 KiB through a 256-byte-per-clock LDS), whatever the banks.
+  constexpr uint32_t kColStride = kInstBlock + 4;
+  __shared__ float4 s_mat[4 * kColStride];
   const uint32_t block_first = blockIdx.x * kInstBlock;
   const uint32_t in_block = min((uint32_t)kInstBlock, instance_count - block_first);
   const float4* src = matrices + 4ull * block_first;
@@ -118,13 +124,12 @@ __global__ __launch_bounds__(kInstBlock) void instance_aabb_kernel(const float4*
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const uint32_t k = t + (uint32_t)j * kInstBlock;
-    if (k < 4u * in_block) s_mat[k + (k >> 4)] = staged[j];
+    if (k < 4u * in_block) s_mat[(k & 3u) * kColStride + (k >> 2)] = staged[j];
   }
   __syncthreads();
   if (t >= in_block) return;
   const float4 lo = mesh_aabb[2u * m], hi = mesh_aabb[2u * m + 1u];
-  const float4* cols = s_mat + 4u * t + (t >> 2);
-  const float4 c0 = cols[0], c1 = cols[1], c2 = cols[2], c3 = cols[3];
+  const float4 c0 = s_mat[t], c1 = s_mat[kColStride + t], c2 = s_mat[2u * kColStride + t], c3 = s_mat[3u * kColStride + t];
   const float m0[3] = {c0.x, c0.y, c0.z}, m1[3] = {c1.x, c1.y, c1.z}, m2[3] = {c2.x, c2.y, c2.z}, m3[3] = {c3.x, c3.y, c3.z};
   // corner order of /root/reference/src/vkmodel.cpp:172-173
   const float cx[8] = {lo.x, hi.x, lo.x, lo.x, hi.x, hi.x, lo.x, hi.x};
