@@ -7,8 +7,9 @@ Headline workload (BASELINE.json configs[1]): deferred lighting resolve of a 384
 G-buffer with 256 point lights, 8-bit output, inputs resident in HBM.  One "step" = one resolve of
 one frame.  The 2^22-instance frustum cull (configs[2]) is timed in the same run and reported in
 the "cull" object.  For N > 1 every rank shades its own frame (frame-batch parallelism, no
-collective in the timed region: weak scaling); the screen-band variant of ONE frame with an RCCL
-all_gather of the bands is timed as well and reported under "band_sharded".
+collective in the timed region: weak scaling); the screen-band variant of ONE frame, its bands
+gathered on rank 0 over RCCL behind the next frame's resolve, is timed as well and reported under
+"band_sharded" with the gathered frame verified against rank 0's own whole-frame resolve.
 
 Prints ONE JSON line on rank 0.
 """
