@@ -31,6 +31,12 @@ HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E (spec)
 VALU_FP32_PEAK = 157.3e12  # FLOP/s, vector FP32 (spec)
 
 
+# Kernel names under which the committed PMC passes (profiles/rNN_pmc.json) list the HBM traffic per launch.
+PMC_DEFERRED = "deferred_kernel<0, false>"
+PMC_TILED = ("light_bins_kernel", "tile_lists_kernel<0>", "deferred_list_kernel<0>")
+PMC_CULL = {"atomic": ("cull_init_cmds", "cull_atomic_kernel"), "deterministic": ("cull_onepass_kernel",)}
+
+
 def deferred_algorithmic(width, height, lights):
     """Algorithmic work of one resolve: 24 B/pixel (20 read + 4 written, 8-bit output) and
     150 + 117*L FP32 operations per pixel (FMA counted as two)."""
@@ -119,7 +125,7 @@ def bench_callers(ctx, vkr, synth, vdist, args, K, WU, rank, world, barrier, max
     # Radius cutoff with light lists on the analytic scene (coherent depth): the 8K x 4096-light configuration and the
     # two 4K ones.  L_eff = mean number of lights a pixel's loop walked, measured from the lists of the timed frame;
     # frac = max(algorithmic bytes / t / HBM peak, flops(L_eff) / t / VALU peak).
-    tiled_kernels = ("light_bins_kernel", "tile_lists_kernel<0>", "deferred_kernel<0, true, true>")
+    tiled_kernels = PMC_TILED
 
     def tiled_line(Wt, Ht, Lt, Rt, profiled=False):
         gbt = gb if (Wt, Ht) == (W, H) else vkr.GBuffer(ctx, Wt, Ht)
@@ -277,7 +283,7 @@ def main():
     dbytes, dflops = deferred_algorithmic(W, H, L)
     pmc, pmc_file = profiled_traffic()
     default_workload = (W, H, L, args.instances, args.meshes) == (3840, 2160, 256, 1 << 22, 1024)
-    d_traffic = pmc.get("deferred_kernel<0, false, false>") if default_workload else None
+    d_traffic = pmc.get(PMC_DEFERRED) if default_workload else None
     ach_flops = dflops / (kern_ms * 1e-3)
     ach_bytes = dbytes / (kern_ms * 1e-3)
 
@@ -435,7 +441,7 @@ def main():
             call_ms = e1.elapsed_ms_since(e0) / K
             vis = int(css[0].results()["cmds"]["instanceCount"].sum())
             cb = cull_algorithmic(N, vis, M)
-            kernels = ("cull_init_cmds", "cull_atomic_kernel") if flags == 0 else ("cull_onepass_kernel",)
+            kernels = PMC_CULL[mode_name]
             c_traffic = sum(pmc[k] for k in kernels) if default_workload and all(k in pmc for k in kernels) else None
             cull[mode_name] = {"value": float(N) * K * world / cw / 1e9, "unit": "G instances/s", "ms_per_call": call_ms,
                                "visible_fraction": vis / N,

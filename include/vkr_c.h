@@ -120,6 +120,10 @@ typedef struct vkr_image2d {
                                          and light; allocated or grown inside the call, released with the context). */
 #define VKR_DEFERRED_NO_TILE_LISTS 2u /* with RADIUS_CUTOFF: apply the cutoff per pixel only and loop over the whole
                                          light table (diagnostic; results are bit-identical to the tiled path) */
+#define VKR_DEFERRED_WHOLE_TILE_WORKGROUPS 4u /* whole-table loop: always one 256-thread workgroup per 32 x 32 pixel
+                                         tile.  Without it a launch of fewer than four rounds of such workgroups (a
+                                         small frame, a screen band) runs as single-wave workgroups over 32 x 8 pixel
+                                         tiles, which keeps the last round full (diagnostic; bit-identical results) */
 
 /* One dispatch of /root/reference/shaders/deferred.comp (main, :98-131) as recorded at
  * /root/reference/src/main.cpp:222-226.  Bindings follow main.cpp:163-167,190-196:

@@ -134,6 +134,28 @@ def test_band_rows_match_full_frame(vkr, synth, ctx):
         assert np.all(band[rest] == 0)  # rows outside the band are untouched
 
 
+@pytest.mark.parametrize("w,h,lights", [(64, 36, 13), (131, 77, 200), (37, 9, 700), (5, 3, 1), (256, 250, 129)])
+def test_workgroup_shapes_give_the_same_bytes(vkr, synth, ctx, w, h, lights):
+    """A launch of a few rounds of workgroups (small frames, screen bands) runs as single-wave workgroups over
+    32 x 8 pixel tiles, larger ones as four-wave workgroups over 32 x 32; VKR_DEFERRED_WHOLE_TILE_WORKGROUPS forces
+    the latter.  Same pixels, same light order: every output format, and the whole-table loop with the radius rule,
+    must come out byte for byte the same, on extents that are no multiple of either tile."""
+    case = synth.deferred_case(w, h, lights, config_index=5)
+    for fmt in (vkr.FORMAT_R32G32B32A32_SFLOAT, vkr.FORMAT_R16G16B16A16_SFLOAT, vkr.FORMAT_R8G8B8A8_UNORM, vkr.FORMAT_B8G8R8A8_UNORM):
+        fine, _ = run_deferred_gpu(vkr, ctx, case, fmt)
+        coarse, _ = run_deferred_gpu(vkr, ctx, case, fmt, flags=vkr.DEFERRED_WHOLE_TILE_WORKGROUPS)
+        assert np.array_equal(fine, coarse), fmt
+    case["push"] = case["push"].copy()
+    case["push"][3] = 80.0
+    flags = vkr.DEFERRED_RADIUS_CUTOFF | vkr.DEFERRED_NO_TILE_LISTS
+    fine, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT, flags=flags)
+    coarse, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT, flags=flags | vkr.DEFERRED_WHOLE_TILE_WORKGROUPS)
+    assert np.array_equal(fine, coarse)
+    r0, r1 = h // 3, h - h // 4
+    band, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT, flags=flags, rows=(r0, r1))
+    assert np.array_equal(band[r0:r1], coarse[r0:r1])
+
+
 @pytest.mark.parametrize("w,h,lights,radius", [(64, 36, 64, 150.0), (96, 40, 700, 60.0), (70, 33, 1500, 1e6), (33, 70, 300, 5.0)])
 def test_radius_cutoff_extension(vkr, synth, oracle, ctx, w, h, lights, radius):
     """Opt-in extension (not in the reference): a light contributes only where dist^2 < radius^2.  The kernel

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--lights", type=int, default=256)
     ap.add_argument("--ranks", type=int, nargs="+", default=[1, 2, 4, 8])
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--whole-tiles", action="store_true", help="force one 256-thread workgroup per 32 x 32 tile (VKR_DEFERRED_WHOLE_TILE_WORKGROUPS)")
     a = ap.parse_args()
     vkr = importlib.import_module("vk-renderer_amd")
     synth = importlib.import_module("vk-renderer_amd.synth")
@@ -30,12 +31,13 @@ def main():
     gb = vkr.GBuffer(ctx, a.width, a.height).upload(case["gbuf"])
     lights = ctx.buffer_from(case["lights"])
     out = ctx.image(vkr.FORMAT_R8G8B8A8_UNORM, a.width, a.height)
-    res = {"width": a.width, "height": a.height, "lights": a.lights, "bands": {}}
+    res = {"width": a.width, "height": a.height, "lights": a.lights, "whole_tiles": a.whole_tiles, "bands": {}}
     for world in a.ranks:
         times = []
         for rank in range(world):
             r0, r1 = vdist.band_rows(a.height, world, rank)
-            args = vkr.make_deferred_args(gb, out, lights, a.lights, case["push"], row0=r0, rows=r1 - r0)
+            args = vkr.make_deferred_args(gb, out, lights, a.lights, case["push"], row0=r0, rows=r1 - r0,
+                                          flags=vkr.DEFERRED_WHOLE_TILE_WORKGROUPS if a.whole_tiles else 0)
             for _ in range(15 if not times else 3):
                 ctx.deferred_resolve(args)
             ctx.wait_idle()

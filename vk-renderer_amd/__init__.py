@@ -29,6 +29,7 @@ FORMAT_D32_SFLOAT = 126
 BUFFER_DEVICE, BUFFER_HOST_VISIBLE = 0, 1
 DEFERRED_RADIUS_CUTOFF = 1
 DEFERRED_NO_TILE_LISTS = 2
+DEFERRED_WHOLE_TILE_WORKGROUPS = 4
 CULL_DETERMINISTIC = 1
 NOALLOC_MAX_INSTANCES = 1 << 22
 LIGHT_STRIDE = 48

@@ -367,10 +367,17 @@ __device__ __forceinline__ void store_float4x4(uint8_t* orow, uint32_t x0, uint3
 // the next vector instruction): 2.331 against 2.331 ms.  The loop's non-vector instructions are not what it waits for.
 // launch bound: 4 waves per SIMD (<= 128 VGPRs); measured 1-2 % faster than the 3 waves the allocator
 // settles on unprompted.
-template <int kOutMode, bool kRadius>
-__global__ __launch_bounds__(256, 4) void deferred_kernel(const DeferredParams p) {
-  __shared__ float4 s_light[2 * kChunk + 4];  // +1 pair: the prefetch of the last iteration reads past the list
-  __shared__ uint32_t s_stash[14][256];  // rows: see kRow* below
+// kWaves = waves per workgroup: the tile is 32 x (8 * kWaves) pixels and the LDS chunk 128 * kWaves lights.  Four
+// waves (32 x 32) is the form for whole frames; single-wave workgroups are for launches of a few rounds of
+// workgroups only (a screen band of a frame split over several GPUs: 270 rows of a 4K frame are 1080 four-wave
+// workgroups on 1024 slots, i.e. one round and a second one for the last 56, 0.40 ms where an eighth of the
+// whole frame's time is 0.30 ms), where a four times finer grain keeps the last round full.
+template <int kOutMode, bool kRadius, int kWaves>
+__global__ __launch_bounds__(64 * kWaves, 4) void deferred_kernel(const DeferredParams p) {
+  constexpr uint32_t kThreads = 64u * kWaves, kTileRows = 8u * kWaves, kLightChunk = 128u * kWaves;
+  static_assert(kLightChunk <= (uint32_t)kChunk, "chunk beyond the staging area's size");
+  __shared__ float4 s_light[2 * kLightChunk + 4];  // +1 pair: the prefetch of the last iteration reads past the list
+  __shared__ uint32_t s_stash[14][kThreads];  // rows: see kRow* below
   constexpr bool kIs8Bit = kOutMode == kOutRgba8 || kOutMode == kOutBgra8;
   const uint32_t t = threadIdx.x;
   const float4* __restrict__ lights = reinterpret_cast<const float4*>(p.lights);
@@ -385,11 +392,11 @@ __global__ __launch_bounds__(256, 4) void deferred_kernel(const DeferredParams p
   const uint32_t tile_x = blockIdx.x, tile_y = blockIdx.y;
   const uint32_t count = L;  // lights this tile walks
   const uint32_t x0 = tile_x * 32u + (t & 7u) * 4u;
-  const uint32_t y = tile_y * 32u + (t >> 3);
+  const uint32_t y = tile_y * kTileRows + (t >> 3);
   const bool inside = (x0 < p.width) && (y < p.height);
   // lanes outside the image shade the tile's first group (in bounds by construction) and store nothing
   const uint32_t lx = inside ? x0 : tile_x * 32u;
-  const uint32_t ly = inside ? y : tile_y * 32u;
+  const uint32_t ly = inside ? y : tile_y * kTileRows;
   const uint32_t y_full = ly + p.row_offset;
 
   const uint4 alb4 = *reinterpret_cast<const uint4*>(p.albedo + (size_t)ly * p.pitch_albedo + (size_t)lx * 4u);
@@ -480,11 +487,11 @@ __global__ __launch_bounds__(256, 4) void deferred_kernel(const DeferredParams p
     };
     const float4 black_pos = make_float4(0.0f, 0.0f, 1e18f, 0.0f), black_col = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 
-    for (uint32_t base = 0; base < count; base += kChunk) {
-      const uint32_t n = min((uint32_t)kChunk, count - base);
+    for (uint32_t base = 0; base < count; base += kLightChunk) {
+      const uint32_t n = min(kLightChunk, count - base);
       const uint32_t n2 = (n + 1u) & ~1u;
       __syncthreads();  // previous chunk fully consumed
-      for (uint32_t i = t; i < n2; i += 256u) {
+      for (uint32_t i = t; i < n2; i += kThreads) {
         float4 lp = black_pos, lc = black_col;
         if (i < n) {
           lp = lights[3u * (base + i)];       // pos.xyz, opening_angle (unused)
@@ -772,7 +779,7 @@ __device__ __forceinline__ TileBounds tile_bounds(const DeferredParams& p, uint3
 // tile's list.  A tile that no light reaches is finished here: every light sum of deferred.comp:120-129 is
 // zero for its pixels, whatever their positions and normals are, so they are their ambient term
 // (deferred.comp:107) - 12 bytes per pixel instead of 24, and the shading kernel never sees the tile.  The other
-// tiles are queued for deferred_kernel<.., true, true>.
+// tiles are queued for deferred_list_kernel.
 template <int kOutMode>
 __global__ __launch_bounds__(256) void tile_lists_kernel(const DeferredParams p, const TileListOut o) {
   __shared__ uint32_t s_lit[4], s_class[4];
@@ -1014,15 +1021,20 @@ constexpr uint32_t kBinMinLights = 256;           // below this every tile tests
 constexpr uint64_t kBinMaxEntries = 64ull << 20;  // 256 MiB of indices
 constexpr uint32_t kListCap = kChunk;             // entries per tile list: one LDS chunk
 constexpr uint32_t kListMaxLights = 65536;        // list entries are 16-bit light indices
+constexpr uint32_t kFineRounds = 4;               // whole-table launches shorter than this many rounds use single-wave workgroups
 
 template <int kOutMode>
 hipError_t launch_mode(const DeferredParams& p, const TileListOut* lists, uint32_t cu_count, hipStream_t stream) {
   const dim3 grid((p.width + 31u) / 32u, (p.height + 31u) / 32u, 1u);
   const bool radius = (p.flags & 1u) != 0u;
-  if (!radius) {
-    hipLaunchKernelGGL((deferred_kernel<kOutMode, false>), grid, dim3(256), 0, stream, p);
-  } else if (!lists) {
-    hipLaunchKernelGGL((deferred_kernel<kOutMode, true>), grid, dim3(256), 0, stream, p);
+  // fewer than kFineRounds rounds of four-wave workgroups (four of them fit a CU): single-wave workgroups
+  const bool fine = (p.flags & 4u) == 0u && (uint64_t)grid.x * grid.y < (uint64_t)kFineRounds * 4u * cu_count;
+  const dim3 fine_grid(grid.x, (p.height + 7u) / 8u, 1u);
+  if (lists == nullptr) {
+    if (!radius && !fine) hipLaunchKernelGGL((deferred_kernel<kOutMode, false, 4>), grid, dim3(256), 0, stream, p);
+    if (!radius && fine) hipLaunchKernelGGL((deferred_kernel<kOutMode, false, 1>), fine_grid, dim3(64), 0, stream, p);
+    if (radius && !fine) hipLaunchKernelGGL((deferred_kernel<kOutMode, true, 4>), grid, dim3(256), 0, stream, p);
+    if (radius && fine) hipLaunchKernelGGL((deferred_kernel<kOutMode, true, 1>), fine_grid, dim3(64), 0, stream, p);
   } else {
     const uint32_t tiles = p.tiles_x * p.tiles_y;
     hipLaunchKernelGGL((tile_lists_kernel<kOutMode>), dim3((tiles + 3u) / 4u), dim3(256), 0, stream, p, *lists);

@@ -152,7 +152,7 @@ int32_t run_deferred(vkr_context* ctx, const vkr_deferred_args* a) {
   const uint32_t full_h = a->full_height ? a->full_height : h;
   if ((uint64_t)a->row_offset + h > full_h)
     return fail(VKR_ERR_INVALID_ARGUMENT, "row_offset %u + height %u exceeds full_height %u", a->row_offset, h, full_h);
-  if (a->flags & ~(VKR_DEFERRED_RADIUS_CUTOFF | VKR_DEFERRED_NO_TILE_LISTS)) return fail(VKR_ERR_INVALID_ARGUMENT, "unknown flags 0x%x", a->flags);
+  if (a->flags & ~(VKR_DEFERRED_RADIUS_CUTOFF | VKR_DEFERRED_NO_TILE_LISTS | VKR_DEFERRED_WHOLE_TILE_WORKGROUPS)) return fail(VKR_ERR_INVALID_ARGUMENT, "unknown flags 0x%x", a->flags);
   if (a->flags & VKR_DEFERRED_RADIUS_CUTOFF) {
     const float r = a->push[3];
     // the in-kernel cutoff is the exact step clamp((r^2 - d^2) * 2^80): r^2 must stay within its exact range

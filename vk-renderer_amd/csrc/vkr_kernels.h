@@ -21,7 +21,7 @@ struct DeferredParams {
   uint32_t full_height;        // height of the full frame (UV denominator)
   uint32_t light_count;
   uint32_t out_mode;
-  uint32_t flags;              // bit 0: radius cutoff
+  uint32_t flags;              // bit 0: radius cutoff; bit 1: no light lists; bit 2: always four-wave workgroups
   float cam[3];
   float radius2;
   float inv_vp[16];            // column-major
