@@ -22,7 +22,7 @@ UNITS = [
     # -falign-loops=32: loop headers on 32-byte boundaries (harmless; the placement sensitivity once seen
     # here was the transcendental issue hazard that the kernel now avoids explicitly).
     ("deferred.hip", ["-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-falign-loops=32"]),
-    ("cull.hip", ["-O3", "-ffp-contract=off", "-fno-slp-vectorize"]),
+    ("cull.hip", ["-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]),
     ("scene.hip", ["-O3", "-ffp-contract=off", "-fno-slp-vectorize"]),
     ("gbuffer.hip", ["-O3", "-ffp-contract=off", "-fno-slp-vectorize"]),
     ("vkr_api.hip", ["-O2"]),

@@ -85,37 +85,12 @@ __device__ __forceinline__ bool any_pending(const uint64_t (&pend)[kAtomicPerLan
   return all != 0ull;
 }
 
-// Loads and tests the instances of this lane.  Instance of (wave chunk, row k, lane l) is
-// chunk*256 + k*64 + l, so every wave-level load covers 1 KiB of contiguous memory.
+// Visibility and local mesh index (global id - first_mesh) of this lane's instances.  Instance of (wave chunk,
+// row k, lane l) is chunk*256 + k*64 + l, so every wave-level load covers 1 KiB of contiguous memory.
 struct LaneWork {
   bool vis[kAtomicPerLane];
-  uint32_t mesh[kAtomicPerLane];  // local mesh index (global id - first_mesh)
+  uint32_t mesh[kAtomicPerLane];
 };
-
-__device__ __forceinline__ LaneWork test_four(const CullParams& p, uint32_t chunk_base, uint32_t lane, bool& bad) {
-  float4 mn[kAtomicPerLane], mx[kAtomicPerLane];
-  bool in[kAtomicPerLane];
-#pragma unroll
-  for (uint32_t k = 0; k < kAtomicPerLane; ++k) {
-    const uint32_t i = chunk_base + k * 64u + lane;
-    in[k] = i < p.instance_count;
-    const uint32_t ic = in[k] ? i : 0u;
-    mn[k] = load_stream(p.aabb_min + ic);
-    mx[k] = load_stream(p.aabb_max + ic);
-  }
-  LaneWork w;
-#pragma unroll
-  for (uint32_t k = 0; k < kAtomicPerLane; ++k) {
-    w.mesh[k] = __float_as_uint(mn[k].w) - p.first_mesh;
-    bool v = in[k] && aabb_visible(mn[k], mx[k], p.planes);
-    if (v && w.mesh[k] >= p.mesh_count) {
-      bad = true;
-      v = false;
-    }
-    w.vis[k] = v;
-  }
-  return w;
-}
 
 // Counts accumulate in cmd_out[m].instanceCount, zeroed by cull_init_cmds in the launch before.
 // Folding both into one launch was tried twice and is no faster than the 4.5 us the extra launch costs:
@@ -124,21 +99,63 @@ __device__ __forceinline__ LaneWork test_four(const CullParams& p, uint32_t chun
 // (__threadfence) and stall for about as long as the launch took; with an agent-scope *acquire* in
 // the poll it is 3x slower, because that invalidates the XCD's L2 once per wave (the L2s of the
 // eight XCDs are not coherent with each other);  (b) a "last block" ticket at the end was 4x slower.
-// Requesting the next chunk's boxes before working on the current one (so that the returning atomic waits
-// alongside those loads) was measured too: 31-32 us per call against 30, at any grid size.  So was halving
-// the number of atomics by letting a wave test two load groups of 256 consecutive instances one after the
-// other before its atomic: 32 us (four groups: 40 us) - short-lived waves matter more than fewer atomics.
+//
+// A wave owns chunks of 256 consecutive instances.  Memory operations of a wave return in the order they were
+// issued, so the order of the requests decides what a wait covers: the atomic that reserves the wave's slots
+// goes out first, then the load of the segment base, then the boxes of the wave's NEXT chunk, and the wait for
+// the atomic's result leaves those eight loads in flight (s_waitcnt vmcnt(8)).  30.5 -> 27.4 us per call at
+// 2^22 instances against a loop that asked for each chunk's boxes at the top of its trip.  What that takes:
+//   * the compiler's wave-level atomic optimiser is off for this file (-amdgpu-atomic-optimizer-strategy=None):
+//     it would wrap the one-lane atomic in a reduction of its own and wait for the result straight away;
+//   * the segment base is asked for through a vector register and made uniform only after the requests, else
+//     the value is moved to a scalar register, and waited for, where it is requested;
+//   * the requests are unconditional (a wave without a next chunk asks for instance 0): a wait that follows a
+//     branch with and a branch without requests is sized for the branch without;
+//   * the unused fourth component of the max corners counts as read when a box is tested: a register that is
+//     free while its load is in flight is handed to a temporary, whose write then has to wait for that load.
+// Measured alternatives (us per call): the requests ahead of the atomic, so that the atomic's result comes back
+// behind them: 31-32; two load groups of 256 instances per atomic: 32 (four: 40); 128 instances per chunk: 30.5;
+// 512: 30.7; grids of 1024 / 1280 / 1536 / 1792 / 2048 workgroups: 28.4 / 28.2 / 27.4 / 28.4 / 27.5.
 __global__ __launch_bounds__(256) void cull_atomic_kernel(const CullParams p, uint32_t chunk_count) {
   const uint32_t lane = lane_id();
   const uint32_t wave = (blockIdx.x * kBlockThreads + threadIdx.x) >> 6;
   const uint32_t wave_stride = (gridDim.x * kBlockThreads) >> 6;
+  const uint32_t n = p.instance_count;
   bool bad = false;
+  float4 mn[kAtomicPerLane], mx[kAtomicPerLane];
+  auto request_boxes = [&](uint32_t chunk) {
+#pragma unroll
+    for (uint32_t k = 0; k < kAtomicPerLane; ++k) {
+      const uint32_t i = chunk * kAtomicChunk + k * 64u + lane;
+      const uint32_t ic = i < n ? i : 0u;
+      mn[k] = load_stream(p.aabb_min + ic);
+      mx[k] = load_stream(p.aabb_max + ic);
+    }
+  };
+  if (wave < chunk_count) request_boxes(wave);
+#pragma unroll 1
   for (uint32_t chunk = wave; chunk < chunk_count; chunk += wave_stride) {
     const uint32_t chunk_base = chunk * kAtomicChunk;
-    LaneWork w = test_four(p, chunk_base, lane, bad);
+    LaneWork w;
+#pragma unroll
+    for (uint32_t k = 0; k < kAtomicPerLane; ++k) {
+      const uint32_t i = chunk_base + k * 64u + lane;
+      w.mesh[k] = __float_as_uint(mn[k].w) - p.first_mesh;
+      // the unused fourth component counts as read here: a register that is free while its load is still in
+      // flight would be handed to a temporary, whose write has to wait for that load
+      asm volatile("" : : "v"(mx[k].w));
+      bool v = i < n && aabb_visible(mn[k], mx[k], p.planes);
+      if (v && w.mesh[k] >= p.mesh_count) {
+        bad = true;
+        v = false;
+      }
+      w.vis[k] = v;
+    }
     uint64_t pend[kAtomicPerLane];
 #pragma unroll
     for (uint32_t k = 0; k < kAtomicPerLane; ++k) pend[k] = __ballot(w.vis[k]);
+    bool next_requested = false;
+    const uint32_t next = chunk + wave_stride;
     // one iteration per distinct mesh among this wave's visible instances (usually one)
     while (any_pending(pend)) {
       uint32_t m = 0;
@@ -154,13 +171,24 @@ __global__ __launch_bounds__(256) void cull_atomic_kernel(const CullParams p, ui
         pend[k] &= ~same[k];
       }
       uint32_t base = 0;
-      if (lane == 0u) base = atomicAdd(&p.cmd_out[m].instanceCount, total);
-      base = __builtin_amdgcn_readfirstlane(base) + p.mesh_base[m];
+      if (lane == 0u) base = __hip_atomic_fetch_add(&p.cmd_out[m].instanceCount, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // where the mesh's segment begins: asked for through a vector register, so that the value is not moved to a
+      // scalar register (and waited for) the moment it is requested
+      uint32_t m_lane;
+      asm volatile("v_mov_b32 %0, %1" : "=v"(m_lane) : "s"(m));
+      uint32_t segment = p.mesh_base[m_lane];
+      if (!next_requested) {
+        asm volatile("" ::: "memory");  // the loads below stay behind the atomic
+        request_boxes(next < chunk_count ? next : 0xFFFFFFFFu / kAtomicChunk);  // beyond the end: every lane reads instance 0
+        next_requested = true;
+      }
+      asm volatile("" : "+v"(base), "+v"(segment) : : "memory");  // first use of the two results: after the requests
+      base = __builtin_amdgcn_readfirstlane(base) + __builtin_amdgcn_readfirstlane(segment);
 #pragma unroll
       for (uint32_t k = 0; k < kAtomicPerLane; ++k) {
         if (w.vis[k] && w.mesh[k] == m) {
           const uint32_t slot = base + rank_in(same[k]);
-          if (slot < p.instance_count)
+          if (slot < n)
             p.visible[slot] = p.first_instance + chunk_base + k * 64u + lane;
           else
             bad = true;
@@ -168,6 +196,7 @@ __global__ __launch_bounds__(256) void cull_atomic_kernel(const CullParams p, ui
         base += (uint32_t)__popcll(same[k]);
       }
     }
+    if (!next_requested && next < chunk_count) request_boxes(next);
   }
   if (bad && p.error_flag) *p.error_flag = 1u;
 }
