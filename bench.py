@@ -106,6 +106,20 @@ def bench_callers(ctx, vkr, synth, vdist, args, K, WU, rank, world, barrier, max
     out["gbuffer_encode"] = {"value": W * H / (ms * 1e-3) / 1e9, "unit": "Gpixel/s", "ms_per_call": ms,
                              "roofline": {"bound": "hbm", "achieved": byt / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                           "frac": byt / (ms * 1e-3) / HBM_PEAK, "traffic": pmc.get("gbuffer_encode_kernel"), "algorithmic_bytes": byt}}
+    # both shader stages of the G-buffer pass per pixel (tangent frame from the pixel's model matrix + normal map):
+    # five float4 planes and depth in, the pixel's matrix from a 4096-entry table (index constant over 64-pixel runs)
+    idx = np.repeat(rng.integers(0, 4096, (H, (W + 63) // 64), dtype=np.uint32), 64, axis=1)[:, :W]
+    nobj = rng.standard_normal((H, W, 4), dtype=np.float32)
+    nobj[..., 3] = idx.view(np.float32)
+    planes = [ctx.buffer_from(rng.random((H, W, 4), dtype=np.float32)) for _ in range(3)]
+    planes += [ctx.buffer_from(nobj), ctx.buffer_from(rng.standard_normal((H, W, 4), dtype=np.float32)), ctx.buffer_from(rng.random((H, W), dtype=np.float32)),
+               ctx.buffer_from(rng.standard_normal((4096, 16), dtype=np.float32))]
+    del nobj, idx
+    ms = timed(ctx, lambda: frame.gbuffer_encode_surfaces(ctx, gb, *planes, 4096), K, WU)
+    byt = W * H * 104.0  # 84 bytes of float planes in, 20 bytes of attachments out (the matrices come from the caches)
+    out["gbuffer_encode_surfaces"] = {"value": W * H / (ms * 1e-3) / 1e9, "unit": "Gpixel/s", "ms_per_call": ms,
+                                      "roofline": {"bound": "hbm", "achieved": byt / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                                   "frac": byt / (ms * 1e-3) / HBM_PEAK, "traffic": pmc.get("gbuffer_surface_kernel"), "algorithmic_bytes": byt}}
     del planes
 
     cam = synth.reference_camera(W, H)

@@ -425,6 +425,35 @@ typedef struct vkr_gbuffer_encode_args {
 } vkr_gbuffer_encode_args;
 VKR_API int32_t vkr_gbuffer_encode(vkr_context* ctx, const vkr_gbuffer_encode_args* args);
 
+/* Both stages of the reference's G-buffer pass for one surface sample per pixel (a software producer that keeps
+ * the raster pass's interpolated attributes per pixel, visibility-buffer style):
+ *   /root/reference/shaders/offscreen.vert:28-35  M = modelMatrices[index]; N = normalize(vec3(M * vec4(inNormal, 0)));
+ *                                                 T = normalize(vec3(M * vec4(inTangent, 0))); B = cross(N, T);
+ *   /root/reference/shaders/offscreen.frag:13-16  outColor, outSpecular = the two texels; outNormal =
+ *                                                 vec4(mat3(T, B, N) * normalize(normalTexel.xyz * 2 - 1), 1),
+ * then the attachment write conversions of vkr_gbuffer_encode.  Arithmetic, binary32 without fused multiply-add,
+ * divisions and square roots correctly rounded: vec3(M * vec4(v, 0)) = (M[0]*v.x + M[1]*v.y) + M[2]*v.z per row
+ * (the w = 0 term is dropped); normalize(v) = v / sqrt((v.x*v.x + v.y*v.y) + v.z*v.z); cross as written in GLSL;
+ * mat3 * v = (T*v.x + B*v.y) + N*v.z.  Where the raster pass normalises N and T per vertex and interpolates
+ * the matrix, this call builds the matrix per pixel from the pixel's own attributes.
+ * Sources: device arrays of width x height float4 / float, rows contiguous, 16-byte aligned.
+ * normal_obj[p].w holds the pixel's index into model_matrices as uint32 bits (an index >= matrix_count reads
+ * matrix 0); model_matrices = column-major mat4 array, 16-byte aligned (the array of
+ * /root/reference/src/vkmodel.cpp:108-110 that vkr_scene_build_tables fills). */
+typedef struct vkr_gbuffer_surface_args {
+  const void* albedo_texel;   /* float4 per pixel: texture(samplers[texOffset], uv) */
+  const void* specular_texel; /* float4 per pixel: texture(samplers[texOffset + 2], uv) */
+  const void* normal_texel;   /* float4 per pixel: texture(samplers[texOffset + 1], uv), xyz in [0, 1] */
+  const void* normal_obj;     /* float4 per pixel: inNormal.xyz, w = model matrix index */
+  const void* tangent_obj;    /* float4 per pixel: inTangent.xyz, w ignored */
+  const void* depth_f32;      /* float per pixel */
+  const void* model_matrices; /* matrix_count x 16 floats */
+  uint32_t matrix_count;
+  uint32_t reserved;
+  vkr_image2d albedo, material, normal, depth; /* destinations */
+} vkr_gbuffer_surface_args;
+VKR_API int32_t vkr_gbuffer_encode_surfaces(vkr_context* ctx, const vkr_gbuffer_surface_args* args);
+
 /* An analytic test scene (spheres over a checkered ground plane) written straight into the four
  * attachments: per pixel the nearest hit along the camera ray through the pixel centre, depth =
  * clip.z / clip.w of the hit under view_proj (1.0 where nothing is hit, the clear value of

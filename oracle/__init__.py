@@ -374,6 +374,23 @@ def gbuffer_encode(albedo, material, normal, depth) -> dict:
     return out
 
 
+def gbuffer_encode_surfaces(albedo_texel, specular_texel, normal_texel, normal_obj, tangent_obj, depth, matrices) -> dict:
+    """Per-pixel offscreen.vert:28-35 + offscreen.frag:13-16, then the attachment conversions.  Planes (H,W,4) /
+    (H,W); normal_obj[..., 3] carries the matrix index as uint32 bits; matrices (K,16) column-major."""
+    planes = [np.ascontiguousarray(a, np.float32) for a in (albedo_texel, specular_texel, normal_texel, normal_obj, tangent_obj)]
+    depth = np.ascontiguousarray(depth, np.float32)
+    matrices = np.ascontiguousarray(matrices, np.float32).reshape(-1, 16)
+    H, W = depth.shape
+    out = {"albedo": np.zeros((H, W, 4), np.uint8), "material": np.zeros((H, W, 4), np.uint8),
+           "normal": np.zeros((H, W, 4), np.uint16), "depth": np.zeros((H, W), np.float32)}
+    fn = lib().oracle_gbuffer_encode_surfaces
+    fn.restype, fn.argtypes = None, [C.c_void_p] * 7 + [C.c_uint32, C.c_uint64] + [C.c_void_p] * 4
+    fn(*[_ptr(a) for a in planes], _ptr(depth), _ptr(matrices), matrices.shape[0], H * W,
+       _ptr(out["albedo"]), _ptr(out["material"]), _ptr(out["normal"]), _ptr(out["depth"]))
+    out["normal"] = out["normal"].view(np.float16)
+    return out
+
+
 class GBufferScene(C.Structure):
     _fields_ = [("view_proj", C.c_float * 16), ("inv_view_proj", C.c_float * 16), ("camera_pos", C.c_float * 3),
                 ("sphere_count", C.c_uint32), ("ground_plane", C.c_float * 4), ("ground_albedo_a", C.c_float * 3),

@@ -313,6 +313,46 @@ void oracle_gbuffer_encode(const float* albedo, const float* material, const flo
   }
 }
 
+/* offscreen.vert:28-35 + offscreen.frag:13-16 for one surface sample per pixel; see vkr_gbuffer_encode_surfaces for
+ * the evaluation order.  normal_obj[4p+3] carries the matrix index as uint32 bits. */
+static void rotate_dir3(const float* M, const float* v, float* o) {
+  for (int r = 0; r < 3; ++r) o[r] = (M[0 + r] * v[0] + M[4 + r] * v[1]) + M[8 + r] * v[2];
+}
+static void normalize3(float* v) {
+  const float len = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+  v[0] = v[0] / len;
+  v[1] = v[1] / len;
+  v[2] = v[2] / len;
+}
+void oracle_gbuffer_encode_surfaces(const float* albedo_texel, const float* specular_texel, const float* normal_texel, const float* normal_obj,
+                                    const float* tangent_obj, const float* depth, const float* matrices, uint32_t matrix_count, uint64_t pixels,
+                                    uint8_t* o_albedo, uint8_t* o_material, uint16_t* o_normal, float* o_depth) {
+  for (uint64_t p = 0; p < pixels; ++p) {
+    uint32_t mi;
+    memcpy(&mi, normal_obj + 4 * p + 3, 4);
+    if (mi >= matrix_count) mi = 0;
+    const float* M = matrices + 16 * (uint64_t)mi;
+    float N[3], T[3], B[3], m[3], out[4];
+    rotate_dir3(M, normal_obj + 4 * p, N);   /* offscreen.vert:32 */
+    normalize3(N);
+    rotate_dir3(M, tangent_obj + 4 * p, T);  /* :33 */
+    normalize3(T);
+    B[0] = N[1] * T[2] - N[2] * T[1];        /* :34 */
+    B[1] = N[2] * T[0] - N[0] * T[2];
+    B[2] = N[0] * T[1] - N[1] * T[0];
+    for (int c = 0; c < 3; ++c) m[c] = normal_texel[4 * p + c] * 2.0f - 1.0f;  /* offscreen.frag:15 */
+    normalize3(m);
+    for (int c = 0; c < 3; ++c) out[c] = (T[c] * m[0] + B[c] * m[1]) + N[c] * m[2];
+    out[3] = 1.0f;                           /* :16 */
+    for (int c = 0; c < 4; ++c) {
+      o_albedo[4 * p + c] = (uint8_t)unorm8(albedo_texel[4 * p + c]);     /* :13 */
+      o_material[4 * p + c] = (uint8_t)unorm8(specular_texel[4 * p + c]); /* :14 */
+      o_normal[4 * p + c] = half_bits(out[c]);
+    }
+    o_depth[p] = depth[p];
+  }
+}
+
 /* ---------------------------------------------------------------- analytic scene fill
  * The build's own test-scene generator (no reference counterpart beyond the attachment formats and
  * clear values): spheres in table order, then the ground plane; nearest hit with 0 < t < 1 in units

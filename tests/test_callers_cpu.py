@@ -100,6 +100,55 @@ def test_oracle_half_and_unorm_conversions(oracle):
     assert enc[0, 0].tolist() == [0, 0, 255, 0] and enc[0, 1, 0] == 2 and enc[0, 1, 1] == 2 and enc[0, 1, 2] == 254
 
 
+def test_oracle_surface_encode_known_answers(oracle):
+    """offscreen.vert:32-35 + offscreen.frag:15-16 on cases with closed-form answers, and against an independent
+    binary64 numpy evaluation of the GLSL on random input."""
+    def run(n, t, texel, M):
+        one = lambda v: np.asarray(v, np.float32).reshape(1, 1, -1)
+        nobj = np.zeros((1, 1, 4), np.float32)
+        nobj[0, 0, :3] = n
+        tobj = np.zeros((1, 1, 4), np.float32)
+        tobj[0, 0, :3] = t
+        tex = np.ones((1, 1, 4), np.float32)
+        tex[0, 0, :3] = texel
+        z = np.zeros((1, 1, 4), np.float32)
+        return oracle.gbuffer_encode_surfaces(z, z, tex, nobj, tobj, np.zeros((1, 1), np.float32), np.asarray(M, np.float32).reshape(1, 16))["normal"][0, 0].astype(np.float32)
+    I = np.eye(4, dtype=np.float32).reshape(-1)
+    # flat normal map (0.5, 0.5, 1): the geometric normal, normalised; w = 1
+    assert run([0, 0, 2], [3, 0, 0], [0.5, 0.5, 1.0], I).tolist() == [0, 0, 1, 1]
+    # texel (1, 0.5, 0.5) -> tangent direction; (0.5, 1, 0.5) -> bitangent = cross(N, T)
+    assert run([0, 0, 1], [1, 0, 0], [1.0, 0.5, 0.5], I).tolist() == [1, 0, 0, 1]
+    assert run([0, 0, 1], [1, 0, 0], [0.5, 1.0, 0.5], I).tolist() == [0, 1, 0, 1]
+    # a model matrix that turns x into y (column-major: column 0 = (0,1,0)), scales z by 5 and translates: the frame
+    # turns with it, the scale is normalised away, the translation is ignored
+    M = np.zeros((4, 4), np.float32)
+    M[0] = [0, 1, 0, 0]
+    M[1] = [-1, 0, 0, 0]
+    M[2] = [0, 0, 5, 0]
+    M[3] = [7, 8, 9, 1]
+    assert run([0, 0, 1], [1, 0, 0], [1.0, 0.5, 0.5], M.reshape(-1)).tolist() == [0, 1, 0, 1]
+    assert run([0, 0, 1], [1, 0, 0], [0.5, 0.5, 1.0], M.reshape(-1)).tolist() == [0, 0, 1, 1]
+    # second reading of the two shaders in binary64
+    rng = np.random.default_rng(11)
+    h, w, K = 6, 50, 9
+    nobj = rng.normal(size=(h, w, 4)).astype(np.float32)
+    tobj = rng.normal(size=(h, w, 4)).astype(np.float32)
+    tex = rng.uniform(0, 1, (h, w, 4)).astype(np.float32)
+    idx = rng.integers(0, K, (h, w)).astype(np.uint32)
+    nobj[..., 3] = idx.view(np.float32)
+    mats = rng.normal(size=(K, 16)).astype(np.float32)
+    z = np.zeros((h, w, 4), np.float32)
+    got = oracle.gbuffer_encode_surfaces(z, z, tex, nobj, tobj, np.zeros((h, w), np.float32), mats)["normal"].astype(np.float64)
+    M3 = mats.astype(np.float64).reshape(K, 4, 4)[idx][..., :3, :3]          # [..., column, row]
+    rot = lambda v: np.einsum("hwcr,hwc->hwr", M3, v.astype(np.float64))
+    unit = lambda v: v / np.linalg.norm(v, axis=-1, keepdims=True)
+    N, T = unit(rot(nobj[..., :3])), unit(rot(tobj[..., :3]))
+    B = np.cross(N, T)
+    m = unit(tex[..., :3].astype(np.float64) * 2 - 1)
+    want = T * m[..., :1] + B * m[..., 1:2] + N * m[..., 2:3]
+    assert np.abs(got[..., :3] - want).max() < 2e-3 and (got[..., 3] == 1).all()  # half precision of the attachment
+
+
 def test_oracle_camera_known_answers(oracle):
     c = oracle.Camera.default()
     assert c.state().tolist() == [0, 3, 71, 0, 0, -1, 0, -1, 0]
@@ -365,6 +414,7 @@ def test_new_struct_layouts(vkr):
     assert C.sizeof(vkr.GBufferScene) == 208 and vkr.GBufferScene.sphere_count.offset == 140 and vkr.GBufferScene.ground_plane.offset == 144
     assert C.sizeof(vkr.SceneCounts) == 20 and C.sizeof(vkr.SceneTables) == 56 and C.sizeof(vkr.SceneDesc) == 88
     assert vkr.SPHERE_DTYPE.itemsize == 48 and vkr.LIGHT_INFO_DTYPE.itemsize == 48
+    assert C.sizeof(vkr.GBufferSurfaceArgs) == 7 * 8 + 8 + 4 * 24 and vkr.GBufferSurfaceArgs.albedo.offset == 64
     assert vkr.LIGHT_INFO_DTYPE.fields["color"][1] == 16 and vkr.LIGHT_INFO_DTYPE.fields["dir"][1] == 32
 
 

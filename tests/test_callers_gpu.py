@@ -154,6 +154,66 @@ def test_gbuffer_encode_matches_oracle(vkr, ctx, oracle, frame_mod, w, h):
     assert np.array_equal(bits(gb.depth.download(np.float32, 1)), bits(want["depth"]))
 
 
+def surface_case(rng, w, h, matrix_count):
+    """Random per-pixel surface samples: texels, object-space normal / tangent, a matrix index per pixel, and model
+    matrices with rotation, non-uniform scale, shear and translation (the tangent frame must ignore the last)."""
+    albedo = rng.uniform(-0.1, 1.1, (h, w, 4)).astype(np.float32)
+    specular = rng.uniform(-0.1, 1.1, (h, w, 4)).astype(np.float32)
+    normal_texel = rng.uniform(0.0, 1.0, (h, w, 4)).astype(np.float32)
+    normal_texel[rng.random((h, w)) < 0.2] = np.float32([0.5, 0.5, 1.0, 1.0])  # the flat normal map
+    normal_obj = rng.normal(size=(h, w, 4)).astype(np.float32)
+    tangent_obj = rng.normal(size=(h, w, 4)).astype(np.float32)
+    index = rng.integers(0, matrix_count, (h, w)).astype(np.uint32)
+    index[rng.random((h, w)) < 0.02] = matrix_count + 5  # out of range: reads matrix 0
+    normal_obj[..., 3] = index.view(np.float32)
+    matrices = (rng.normal(size=(matrix_count, 16)) * np.exp(rng.uniform(-3, 3, (matrix_count, 1)))).astype(np.float32)
+    depth = rng.random((h, w)).astype(np.float32)
+    return albedo, specular, normal_texel, normal_obj, tangent_obj, depth, matrices
+
+
+@pytest.mark.parametrize("w,h,matrix_count", [(64, 8, 3), (513, 7, 40), (3, 5, 1), (1030, 21, 500)])
+def test_gbuffer_encode_surfaces_matches_oracle(vkr, ctx, oracle, frame_mod, w, h, matrix_count):
+    """offscreen.vert:28-35 + offscreen.frag:13-16 per pixel: bit-exact against the C restatement, on widths either
+    side of the 512-pixel workgroup span."""
+    rng = np.random.default_rng(w * 77 + h)
+    case = surface_case(rng, w, h, matrix_count)
+    gb = vkr.GBuffer(ctx, w, h)
+    bufs = [ctx.buffer_from(a) for a in case]
+    frame_mod.gbuffer_encode_surfaces(ctx, gb, *bufs, matrix_count)
+    ctx.wait_idle()
+    want = oracle.gbuffer_encode_surfaces(*case)
+    assert np.array_equal(gb.albedo.download(np.uint8, 4), want["albedo"])
+    assert np.array_equal(gb.material.download(np.uint8, 4), want["material"])
+    got_n, want_n = gb.normal.download(np.uint16, 4), want["normal"].view(np.uint16)
+    assert np.array_equal(got_n, want_n)
+    assert np.isfinite(want["normal"].astype(np.float32)).all() and (want_n[..., 3] == 0x3C00).all()  # w = 1.0
+    assert np.array_equal(bits(gb.depth.download(np.float32, 1)), bits(want["depth"]))
+
+
+def test_gbuffer_encode_surfaces_degenerate_and_errors(vkr, ctx, oracle, frame_mod):
+    """A zero normal or tangent has no direction: NaN in both (0 / 0), at the same pixels.  Argument checks."""
+    rng = np.random.default_rng(5)
+    case = list(surface_case(rng, 40, 4, 2))
+    case[3][1, 7, :3] = 0.0   # inNormal = 0
+    case[4][2, 9, :3] = 0.0   # inTangent = 0
+    case[2][3, 11, :3] = 0.5  # normal texel * 2 - 1 = 0
+    gb = vkr.GBuffer(ctx, 40, 4)
+    bufs = [ctx.buffer_from(a) for a in case]
+    frame_mod.gbuffer_encode_surfaces(ctx, gb, *bufs, 2)
+    ctx.wait_idle()
+    want = oracle.gbuffer_encode_surfaces(*case)
+    got = gb.normal.download(np.float16, 4)
+    assert np.array_equal(np.isnan(got), np.isnan(want["normal"]))
+    assert np.isnan(got[1, 7, :3]).all() and np.isnan(got[2, 9, :3]).any() and np.isnan(got[3, 11, :3]).all()
+    ok = ~np.isnan(got)
+    assert np.array_equal(got.view(np.uint16)[ok], want["normal"].view(np.uint16)[ok])
+    with pytest.raises(vkr.VkrError, match="matrix"):
+        frame_mod.gbuffer_encode_surfaces(ctx, gb, *bufs, 0)
+    a = vkr.GBufferSurfaceArgs()
+    with pytest.raises(vkr.VkrError):
+        vkr._check(vkr.lib().vkr_gbuffer_encode_surfaces(ctx.handle, a))
+
+
 # ------------------------------------------------------------------------------------------ analytic fill
 
 def fill_case(vkr, synth, frame_mod, w, h, nspheres, seed, **scene_kw):

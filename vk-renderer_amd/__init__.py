@@ -115,6 +115,12 @@ class GBufferEncodeArgs(C.Structure):
                 ("albedo", Image2D), ("material", Image2D), ("normal", Image2D), ("depth", Image2D)]
 
 
+class GBufferSurfaceArgs(C.Structure):
+    _fields_ = [("albedo_texel", C.c_void_p), ("specular_texel", C.c_void_p), ("normal_texel", C.c_void_p), ("normal_obj", C.c_void_p),
+                ("tangent_obj", C.c_void_p), ("depth_f32", C.c_void_p), ("model_matrices", C.c_void_p), ("matrix_count", C.c_uint32),
+                ("reserved", C.c_uint32), ("albedo", Image2D), ("material", Image2D), ("normal", Image2D), ("depth", Image2D)]
+
+
 class GBufferScene(C.Structure):
     _fields_ = [("view_proj", C.c_float * 16), ("inv_view_proj", C.c_float * 16), ("camera_pos", C.c_float * 3),
                 ("sphere_count", C.c_uint32), ("ground_plane", C.c_float * 4), ("ground_albedo_a", C.c_float * 3),
@@ -184,6 +190,7 @@ EXPORTS = {
     "vkr_mesh_aabbs": (C.c_int32, [_P, _P, _P, C.c_uint32, _P]),
     "vkr_instance_aabbs": (C.c_int32, [_P, _P, _P, _P, C.c_uint32, C.c_uint64, _P, _P]),
     "vkr_gbuffer_encode": (C.c_int32, [_P, C.POINTER(GBufferEncodeArgs)]),
+    "vkr_gbuffer_encode_surfaces": (C.c_int32, [_P, C.POINTER(GBufferSurfaceArgs)]),
     "vkr_gbuffer_fill": (C.c_int32, [_P, C.POINTER(GBufferFillArgs)]),
 }
 

@@ -2,6 +2,8 @@
 // (/root/reference/src/main.cpp:111-117: albedo rgba8, material rgba8, normal rgba16f, depth d32f).
 //   encode: the attachment write conversions of /root/reference/shaders/offscreen.frag:13-16 applied
 //           to float planes (what the ROPs do in the reference's raster pass);
+//   surfaces: both shader stages of that pass per pixel (offscreen.vert:28-35 builds the tangent frame from the
+//           pixel's model matrix, offscreen.frag:13-16 applies the normal map), then the same conversions;
 //   fill:   an analytic scene (spheres over a checkered plane) ray-cast per pixel and written in those
 //           formats - test and bench input with coherent depth / normals, not a rasteriser.
 // Both are write-bound streams (20 bytes per pixel).  Contraction is off for this file and every
@@ -77,6 +79,72 @@ __global__ __launch_bounds__(256) void gbuffer_encode_kernel(const float4* __res
       pa[x] = pack_unorm8x4(av[i].x, av[i].y, av[i].z, av[i].w);
       pm[x] = pack_unorm8x4(mv[i].x, mv[i].y, mv[i].z, mv[i].w);
       pn[x] = pack_half4(nv[i].x, nv[i].y, nv[i].z, nv[i].w);
+      pd[x] = dv[i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------- surfaces: offscreen.vert:28-35 + offscreen.frag:13-16 per pixel
+struct Vec3 {
+  float x, y, z;
+};
+// vec3(M * vec4(v, 0)) with M's first three columns c0, c1, c2
+__device__ __forceinline__ Vec3 rotate_dir(const float4 c0, const float4 c1, const float4 c2, const float4 v) {
+  return {(c0.x * v.x + c1.x * v.y) + c2.x * v.z, (c0.y * v.x + c1.y * v.y) + c2.y * v.z, (c0.z * v.x + c1.z * v.y) + c2.z * v.z};
+}
+__device__ __forceinline__ Vec3 normalize3(const Vec3 v) {
+  const float len = sqrtf((v.x * v.x + v.y * v.y) + v.z * v.z);
+  return {v.x / len, v.y / len, v.z / len};
+}
+
+struct SurfaceSources {
+  const float4 *albedo, *specular, *normal_texel, *normal_obj, *tangent_obj;
+  const float* depth;
+  const float4* matrices;
+  uint32_t matrix_count;
+};
+
+// A 256-thread workgroup takes 512 consecutive pixels of one row, lane t the pixels t and t + 256: every load is a
+// fully used 16-byte lane slot.  84 bytes read and 20 written per pixel, plus the pixel's matrix (48 bytes of it;
+// neighbouring pixels name the same one, so those come from the caches): a stream, bound by HBM.
+__global__ __launch_bounds__(256) void gbuffer_surface_kernel(const SurfaceSources s, Planes o) {
+  const uint32_t y = blockIdx.y;
+  const uint32_t x_first = blockIdx.x * 512u + threadIdx.x;
+  const size_t row = (size_t)y * o.width;
+  float4 av[2], sv[2], tv[2], nv[2], gv[2];
+  float dv[2];
+#pragma unroll
+  for (uint32_t i = 0; i < 2u; ++i) {
+    const uint32_t x = x_first + i * 256u;
+    const size_t p = row + (x < o.width ? x : 0u);
+    nv[i] = load_stream(s.normal_obj + p);
+    gv[i] = load_stream(s.tangent_obj + p);
+    tv[i] = load_stream(s.normal_texel + p);
+    av[i] = load_stream(s.albedo + p);
+    sv[i] = load_stream(s.specular + p);
+    dv[i] = __builtin_nontemporal_load(s.depth + p);
+  }
+  uint32_t* pa = reinterpret_cast<uint32_t*>(o.albedo + (size_t)y * o.pitch_albedo);
+  uint32_t* pm = reinterpret_cast<uint32_t*>(o.material + (size_t)y * o.pitch_material);
+  uint2* pn = reinterpret_cast<uint2*>(o.normal + (size_t)y * o.pitch_normal);
+  float* pd = reinterpret_cast<float*>(o.depth + (size_t)y * o.pitch_depth);
+#pragma unroll
+  for (uint32_t i = 0; i < 2u; ++i) {
+    const uint32_t x = x_first + i * 256u;
+    uint32_t mi = __float_as_uint(nv[i].w);
+    if (mi >= s.matrix_count) mi = 0u;
+    const float4 c0 = s.matrices[4u * (size_t)mi], c1 = s.matrices[4u * (size_t)mi + 1u], c2 = s.matrices[4u * (size_t)mi + 2u];
+    const Vec3 N = normalize3(rotate_dir(c0, c1, c2, nv[i]));  // offscreen.vert:32
+    const Vec3 T = normalize3(rotate_dir(c0, c1, c2, gv[i]));  // :33
+    const Vec3 B = {N.y * T.z - N.z * T.y, N.z * T.x - N.x * T.z, N.x * T.y - N.y * T.x};  // :34
+    const Vec3 m = normalize3({tv[i].x * 2.0f - 1.0f, tv[i].y * 2.0f - 1.0f, tv[i].z * 2.0f - 1.0f});  // offscreen.frag:15
+    const float nx = (T.x * m.x + B.x * m.y) + N.x * m.z;
+    const float ny = (T.y * m.x + B.y * m.y) + N.y * m.z;
+    const float nz = (T.z * m.x + B.z * m.y) + N.z * m.z;
+    if (x < o.width) {
+      pa[x] = pack_unorm8x4(av[i].x, av[i].y, av[i].z, av[i].w);  // :13
+      pm[x] = pack_unorm8x4(sv[i].x, sv[i].y, sv[i].z, sv[i].w);  // :14
+      pn[x] = pack_half4(nx, ny, nz, 1.0f);                       // :16
       pd[x] = dv[i];
     }
   }
@@ -290,6 +358,32 @@ int32_t vkr_gbuffer_encode(vkr_context* ctx, const vkr_gbuffer_encode_args* a) {
   hipLaunchKernelGGL(gbuffer_encode_kernel, dim3((o.width + 1023u) / 1024u, o.height), dim3(256), 0, ctx->stream,
                      static_cast<const float4*>(a->albedo_f32), static_cast<const float4*>(a->material_f32), static_cast<const float4*>(a->normal_f32),
                      static_cast<const float*>(a->depth_f32), o);
+  VKR_HIP(hipGetLastError());
+  return VKR_OK;
+}
+
+int32_t vkr_gbuffer_encode_surfaces(vkr_context* ctx, const vkr_gbuffer_surface_args* a) {
+  if (!ctx || !a) return vkr_fail(VKR_ERR_INVALID_ARGUMENT, "vkr_gbuffer_encode_surfaces: null argument");
+  Planes o;
+  if (int32_t rc = planes_from(a->albedo, a->material, a->normal, a->depth, &o)) return rc;
+  const void* sources[] = {a->albedo_texel, a->specular_texel, a->normal_texel, a->normal_obj, a->tangent_obj, a->model_matrices};
+  for (const void* src : sources) {
+    if (!src) return vkr_fail(VKR_ERR_INVALID_ARGUMENT, "vkr_gbuffer_encode_surfaces: null source plane or matrix table");
+    if (reinterpret_cast<uintptr_t>(src) & 15u) return vkr_fail(VKR_ERR_INVALID_ARGUMENT, "vkr_gbuffer_encode_surfaces: float4 sources and matrices must be 16-byte aligned");
+  }
+  if (!a->depth_f32) return vkr_fail(VKR_ERR_INVALID_ARGUMENT, "vkr_gbuffer_encode_surfaces: null depth plane");
+  if (a->matrix_count == 0u) return vkr_fail(VKR_ERR_INVALID_ARGUMENT, "vkr_gbuffer_encode_surfaces: empty matrix table");
+  SurfaceSources s;
+  s.albedo = static_cast<const float4*>(a->albedo_texel);
+  s.specular = static_cast<const float4*>(a->specular_texel);
+  s.normal_texel = static_cast<const float4*>(a->normal_texel);
+  s.normal_obj = static_cast<const float4*>(a->normal_obj);
+  s.tangent_obj = static_cast<const float4*>(a->tangent_obj);
+  s.depth = static_cast<const float*>(a->depth_f32);
+  s.matrices = static_cast<const float4*>(a->model_matrices);
+  s.matrix_count = a->matrix_count;
+  VKR_HIP(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(gbuffer_surface_kernel, dim3((o.width + 511u) / 512u, o.height), dim3(256), 0, ctx->stream, s, o);
   VKR_HIP(hipGetLastError());
   return VKR_OK;
 }

@@ -117,6 +117,18 @@ def gbuffer_encode(ctx: "vkr.Context", gb: "vkr.GBuffer", albedo_f32: "vkr.Buffe
     vkr._check(vkr.lib().vkr_gbuffer_encode(ctx.handle, C.byref(a)))
 
 
+def gbuffer_encode_surfaces(ctx: "vkr.Context", gb: "vkr.GBuffer", albedo_texel: "vkr.Buffer", specular_texel: "vkr.Buffer",
+                            normal_texel: "vkr.Buffer", normal_obj: "vkr.Buffer", tangent_obj: "vkr.Buffer", depth_f32: "vkr.Buffer",
+                            model_matrices: "vkr.Buffer", matrix_count: int):
+    """offscreen.vert:28-35 + offscreen.frag:13-16 per pixel into the four attachments (vkr_gbuffer_encode_surfaces)."""
+    a = vkr.GBufferSurfaceArgs()
+    a.albedo_texel, a.specular_texel, a.normal_texel = albedo_texel.ptr, specular_texel.ptr, normal_texel.ptr
+    a.normal_obj, a.tangent_obj, a.depth_f32 = normal_obj.ptr, tangent_obj.ptr, depth_f32.ptr
+    a.model_matrices, a.matrix_count = model_matrices.ptr, matrix_count
+    a.albedo, a.material, a.normal, a.depth = gb.albedo.desc(), gb.material.desc(), gb.normal.desc(), gb.depth.desc()
+    vkr._check(vkr.lib().vkr_gbuffer_encode_surfaces(ctx.handle, C.byref(a)))
+
+
 class FrameLoop:
     """cull -> G-buffer fill -> deferred resolve per frame, `frames_in_flight` output images in rotation.
 
