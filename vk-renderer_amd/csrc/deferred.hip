@@ -1017,7 +1017,9 @@ __global__ __launch_bounds__(256) void light_bins_kernel(const DeferredParams p,
   if (t == 0u) bin_count[b] = count;
 }
 
-constexpr uint32_t kBinMinLights = 256;           // below this every tile tests the whole table: nothing to gain
+// Below this many lights every tile tests the whole table.  Measured at 4K, radius 25, with / without the coarse
+// bins: 256 lights 38.5 / 38.2 us, 512: 42.2 / 46.3, 1024: 50.4 / 64.8, 2048: 62.7 / 92.0, 4096: 85.9 / 156.5.
+constexpr uint32_t kBinMinLights = 256;
 constexpr uint64_t kBinMaxEntries = 64ull << 20;  // 256 MiB of indices
 constexpr uint32_t kListCap = kChunk;             // entries per tile list: one LDS chunk
 constexpr uint32_t kListMaxLights = 65536;        // list entries are 16-bit light indices
