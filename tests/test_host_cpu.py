@@ -227,6 +227,26 @@ def test_cull_object_code_has_no_float_fma():
     assert fused == [], f"fused multiply-add in cull code: {set(fused)}"
 
 
+@pytest.mark.parametrize("unit", ["deferred", "gbuffer"])
+def test_no_conversion_is_fused_with_arithmetic(unit):
+    """A colour is rounded to binary32 and converted to half from there: a multiply-add folded into the conversion
+    (v_fma_mix*_f16 / v_mad_mix*_f16 round once, straight to half) gives other bits at half-way points."""
+    obj = os.path.join(ROOT, "vk-renderer_amd", "lib", unit + ".o")
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
+    if not (os.path.exists(obj) and all(os.path.exists(t) for t in tools)):
+        pytest.skip("object file or LLVM tools not present")
+    tmp = os.environ.get("TMPDIR", "/tmp")
+    fat, co = os.path.join(tmp, f"vkr_{unit}_mix_fat.bin"), os.path.join(tmp, f"vkr_{unit}_mix_gfx950.co")
+    subprocess.run([tools[0], f"--dump-section=.hip_fatbin={fat}", obj], check=True, capture_output=True)
+    subprocess.run([tools[1], "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}"],
+                   check=True, capture_output=True)
+    asm = subprocess.run([tools[2], "-d", co], capture_output=True, text=True, check=True).stdout
+    assert re.search(r"v_cvt_(pk_)?f16_f32", asm)  # the conversions are there, as instructions of their own
+    mixed = re.findall(r"\bv_(?:fma|mad)_mix(?:lo|hi)_f16\w*", asm)
+    assert mixed == [], f"arithmetic fused with the conversion to half in {unit}: {set(mixed)}"
+
+
 def test_resolve_kernels_use_no_scratch_memory():
     """The resolve kernels that production paths launch (whole-table, list building and list shading, every output format) must keep all
     their state in registers and LDS: a spilled register is HBM traffic of the order of the output itself (an earlier

@@ -34,6 +34,17 @@ def _stale(out: str, deps: list[str]) -> bool:
     return not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
 
 
+def _fingerprint(deps: list[str], cmd: list[str]) -> str:
+    """Contents of everything an object is made from, and the command line: time stamps alone have let an object
+    that was older than its source in content, but not in time, through."""
+    import hashlib
+    h = hashlib.sha256(" ".join(cmd).encode())
+    for d in sorted(deps):
+        with open(d, "rb") as f:
+            h.update(d.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
 def build(force: bool = False, verbose: bool = False, extra_flags: list[str] | None = None) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(LIB_DIR, exist_ok=True)
@@ -43,11 +54,15 @@ def build(force: bool = False, verbose: bool = False, extra_flags: list[str] | N
         s = os.path.join(CSRC, src)
         o = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or _stale(o, [s, __file__] + headers):
-            cmd = [hipcc, "-c", s, "-o", o] + COMMON + flags + (extra_flags or [])
+        cmd = [hipcc, "-c", s, "-o", o] + COMMON + flags + (extra_flags or [])
+        stamp, want = o + ".stamp", _fingerprint([s] + headers, cmd)
+        have = open(stamp).read().strip() if os.path.exists(stamp) else ""
+        if force or have != want or _stale(o, [s, __file__] + headers):
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
+            with open(stamp, "w") as f:
+                f.write(want + "\n")
     if force or _stale(LIB_PATH, objs):
         cmd = [hipcc, "-shared", "-o", LIB_PATH, "--offload-arch=gfx950"] + objs
         if verbose:

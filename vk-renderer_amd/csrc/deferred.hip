@@ -333,17 +333,25 @@ __device__ __forceinline__ void store_rgba8x4(uint8_t* orow, uint32_t x0, uint32
   }
 }
 
+// rgba16f texel of a binary32 colour, alpha 1: each component rounded to binary32 first and to half from there.
+// The components pass through an empty asm statement because the compiler otherwise folds the colour's last
+// multiply-add into the conversion (v_fma_mix*_f16: one rounding, straight to half) - closer to the exact value,
+// but not the bits of "the binary32 result, converted", which is what the other kernels and the CPU evaluation
+// produce; the two differ where the binary32 result lands on a half-way point (seen: 2 pixels of 230 400).
+__device__ __forceinline__ uint2 half_texel(float r, float g, float b) {
+  asm volatile("" : "+v"(r), "+v"(g), "+v"(b));
+  const __half2 lo = __floats2half2_rn(r, g);
+  const __half2 hi = __floats2half2_rn(b, 1.0f);
+  return make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
+}
+
 template <int kOutMode>
 __device__ __forceinline__ void store_float4x4(uint8_t* orow, uint32_t x0, uint32_t valid, const float (&rgb)[4][3]) {
   if (kOutMode == kOutRgba16f) {
     uint2* o = reinterpret_cast<uint2*>(orow) + x0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if ((uint32_t)i < valid) {
-        const __half2 a = __floats2half2_rn(rgb[i][0], rgb[i][1]);
-        const __half2 b = __floats2half2_rn(rgb[i][2], 1.0f);
-        o[i] = make_uint2(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b));
-      }
+      if ((uint32_t)i < valid) o[i] = half_texel(rgb[i][0], rgb[i][1], rgb[i][2]);
     }
   } else {
     float4* o = reinterpret_cast<float4*>(orow) + x0;
@@ -671,11 +679,7 @@ __global__ __launch_bounds__(64, 4) void deferred_list_kernel(const DeferredPara
         uint2* o = reinterpret_cast<uint2*>(orow) + x0;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          if (i == 0 || both) {
-            const __half2 a = __floats2half2_rn(rgb[i][0], rgb[i][1]);
-            const __half2 b = __floats2half2_rn(rgb[i][2], 1.0f);
-            o[i] = make_uint2(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b));
-          }
+          if (i == 0 || both) o[i] = half_texel(rgb[i][0], rgb[i][1], rgb[i][2]);
         }
       } else {
         float4* o = reinterpret_cast<float4*>(orow) + x0;
