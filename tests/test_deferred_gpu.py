@@ -196,6 +196,15 @@ def test_radius_cutoff_with_coarse_bins(vkr, synth, ctx, w, h, lights, radius):
     r0, r1 = h // 3 + 1, h - 7
     band, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT, flags=vkr.DEFERRED_RADIUS_CUTOFF, rows=(r0, r1))
     assert np.array_equal(band[r0:r1], flat[r0:r1])
+    # the other output formats: the list path's bytes are those of the whole-table loop, and the half output is the
+    # binary32 colour converted (not a colour whose last multiply-add was rounded straight to half)
+    for fmt in (vkr.FORMAT_R16G16B16A16_SFLOAT, vkr.FORMAT_R8G8B8A8_UNORM, vkr.FORMAT_B8G8R8A8_UNORM):
+        a, _ = run_deferred_gpu(vkr, ctx, case, fmt, flags=vkr.DEFERRED_RADIUS_CUTOFF)
+        b, _ = run_deferred_gpu(vkr, ctx, case, fmt, flags=vkr.DEFERRED_RADIUS_CUTOFF | vkr.DEFERRED_NO_TILE_LISTS)
+        assert np.array_equal(a, b), fmt
+        if fmt == vkr.FORMAT_R16G16B16A16_SFLOAT:
+            with np.errstate(over="ignore"):
+                assert np.array_equal(a.view(np.uint16), got.astype(np.float16).view(np.uint16))
 
 
 def test_radius_argument_range(vkr, synth, ctx):
