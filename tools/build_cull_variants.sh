@@ -2,7 +2,8 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p vk-renderer_amd/lib/variants
-COMMON="--offload-arch=gfx950 -fPIC -std=c++17 -fvisibility=hidden -fno-slp-vectorize -I include -I vk-renderer_amd/csrc"
+# the production flags of cull.hip (vk-renderer_amd/build.py), so that a variant differs from the library by its -D only
+COMMON="--offload-arch=gfx950 -fPIC -std=c++17 -fvisibility=hidden -fno-slp-vectorize -mllvm -amdgpu-atomic-optimizer-strategy=None -I include -I vk-renderer_amd/csrc"
 while [ $# -gt 0 ]; do
   name=$1; flags=$2; shift 2
   /opt/rocm/bin/hipcc -c ${CULL_SRC:-vk-renderer_amd/csrc/cull.hip} -o /tmp/cull_$name.o $COMMON -O3 -ffp-contract=off $flags
