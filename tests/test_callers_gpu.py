@@ -241,6 +241,51 @@ def test_gbuffer_fill_matches_oracle(vkr, ctx, synth, oracle, frame_mod, w, h, n
         assert 0.2 < hit.mean() <= 1.0  # the scene is really in view
 
 
+@pytest.mark.parametrize("kind", ["tiny_far", "huge_near", "behind", "grazing", "mixed"])
+def test_gbuffer_fill_with_spheres_hard_to_place(vkr, ctx, synth, oracle, frame_mod, kind):
+    """The fill leaves out, per 32 x 32 tile, the spheres no ray of the tile can hit.  Spheres chosen to strain that
+    decision: tiny ones far away (the binary32 discriminant of a ray gives false hits well outside such a sphere's
+    true outline, and the oracle, which tests every sphere on every pixel, reports them), huge ones around and in
+    front of the camera, spheres behind it, spheres whose outline runs along tile borders.  Bit-exact as ever."""
+    w, h = 320, 200
+    cam = synth.reference_camera(w, h)
+    rng = np.random.default_rng({"tiny_far": 1, "huge_near": 2, "behind": 3, "grazing": 4, "mixed": 5}[kind])
+    n = 160
+    spheres = synth.make_spheres(n, 99)
+    pos, fwd = np.asarray(cam["pos"], np.float64), np.array([0.0, 0.0, -1.0])
+    far_points = synth.unproject(cam["inv_vp"], w, h, np.ones((h, w), np.float32))
+    def put(i, centre, radius):
+        spheres[i]["center"] = np.asarray(centre, np.float32)
+        spheres[i]["radius"] = np.float32(radius)
+    for i in range(n):
+        pick = kind if kind != "mixed" else ("tiny_far", "huge_near", "behind", "grazing")[i % 4]
+        side = rng.uniform(-1, 1, 2)
+        if pick == "tiny_far":
+            d = rng.uniform(500, 6000)
+            put(i, pos + fwd * d + np.array([side[0] * d * 0.7, side[1] * d * 0.7, 0.0]), 10 ** rng.uniform(-3, 0))
+        elif pick == "huge_near":
+            d = rng.uniform(1, 80)
+            put(i, pos + fwd * d + np.array([side[0] * d, side[1] * d, 0.0]), d * rng.uniform(0.5, 1.5))  # some contain the camera
+        elif pick == "behind":
+            d = rng.uniform(1, 200)
+            put(i, pos - fwd * d + np.array([side[0] * d, side[1] * d, 0.0]), rng.uniform(0.1, 1.2) * d)
+        else:
+            # centre on the ray through a tile corner, radius a hair more or less than a pixel's width at that depth
+            tx, ty = int(rng.integers(0, w // 32 + 1)) * 32, int(rng.integers(0, h // 32 + 1)) * 32
+            far = far_points[min(ty, h - 1), min(tx, w - 1)]  # the pixel whose corner the tile corner is
+            d = rng.uniform(0.002, 0.02)
+            put(i, pos + (far - pos) * d, np.linalg.norm(far - pos) * d * rng.uniform(0.0005, 0.01))
+    sc = frame_mod.make_gbuffer_scene(cam["vp"], cam["inv_vp"], cam["pos"], n)
+    gb = vkr.GBuffer(ctx, w, h)
+    frame_mod.gbuffer_fill(ctx, gb, ctx.buffer_from(spheres), sc)
+    ctx.wait_idle()
+    want = oracle.gbuffer_fill(bytes(sc), spheres, w, h)
+    assert np.array_equal(gb.albedo.download(np.uint8, 4), want["albedo"])
+    assert np.array_equal(gb.material.download(np.uint8, 4), want["material"])
+    assert np.array_equal(gb.normal.download(np.uint16, 4), want["normal"].view(np.uint16))
+    assert np.array_equal(bits(gb.depth.download(np.float32, 1)), bits(want["depth"]))
+
+
 def test_gbuffer_fill_bands_equal_whole(vkr, ctx, synth, frame_mod):
     w, h = 200, 99
     cam, spheres, sc = fill_case(vkr, synth, frame_mod, w, h, 25, 77)

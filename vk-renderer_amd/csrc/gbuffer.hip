@@ -167,6 +167,8 @@ struct Hit {
 
 __global__ __launch_bounds__(256) void gbuffer_fill_kernel(const FillParams p) {
   __shared__ float4 s_sphere[kSphereChunk];  // camera - centre, |camera - centre|^2 - radius^2
+  __shared__ uint32_t s_index[kSphereChunk];  // table index of each staged sphere
+  __shared__ uint32_t s_kept[2];
   const uint32_t t = threadIdx.x;
   const uint32_t x0 = blockIdx.x * 32u + (t & 7u) * 4u;
   const uint32_t y = blockIdx.y * 32u + (t >> 3);
@@ -196,20 +198,80 @@ __global__ __launch_bounds__(256) void gbuffer_fill_kernel(const FillParams p) {
     a[i] = (dir[i][0] * dir[i][0] + dir[i][1] * dir[i][1]) + dir[i][2] * dir[i][2];
   }
 
+  // The four side faces of the tile's ray pyramid (apex = camera, through the far-plane points of the tile's
+  // corners; the rays of the tile's pixel centres lie inside it): outward unit normals, the same in every thread.
+  float face[4][3];
+  {
+    float corner[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t ex = blockIdx.x * 32u + ((k == 1 || k == 2) ? 32u : 0u);
+      const uint32_t ey = blockIdx.y * 32u + p.row_offset + (k >= 2 ? 32u : 0u);
+      const float cx = (float)ex / (float)p.o.width * 2.0f - 1.0f;
+      const float cyk = (float)ey / (float)p.full_height * 2.0f - 1.0f;
+      const float wx = ((M[0] * cx + M[4] * cyk) + M[8]) + M[12];
+      const float wy = ((M[1] * cx + M[5] * cyk) + M[9]) + M[13];
+      const float wz = ((M[2] * cx + M[6] * cyk) + M[10]) + M[14];
+      const float ww = ((M[3] * cx + M[7] * cyk) + M[11]) + M[15];
+      corner[k][0] = wx / ww - cam[0];
+      corner[k][1] = wy / ww - cam[1];
+      corner[k][2] = wz / ww - cam[2];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float* u = corner[k];
+      const float* w = corner[(k + 1) & 3];
+      const float* in = corner[(k + 2) & 3];
+      float nx = u[1] * w[2] - u[2] * w[1], ny = u[2] * w[0] - u[0] * w[2], nz = u[0] * w[1] - u[1] * w[0];
+      const float len = sqrtf((nx * nx + ny * ny) + nz * nz);
+      const float side = (nx * in[0] + ny * in[1]) + nz * in[2];
+      const float scale = (len > 0.0f && len < 3.0e38f) ? ((side > 0.0f) ? -1.0f : 1.0f) / len : 0.0f;  // degenerate face: culls nothing
+      face[k][0] = nx * scale;
+      face[k][1] = ny * scale;
+      face[k][2] = nz * scale;
+    }
+  }
+
   for (uint32_t base = 0; base < sc.sphere_count; base += kSphereChunk) {
     const uint32_t n = min((uint32_t)kSphereChunk, sc.sphere_count - base);
     __syncthreads();
+    // Staged per sphere: camera - centre and |camera - centre|^2 - radius^2, the same for every pixel - but only
+    // the spheres that a ray of this tile can hit, in table order (the nearest-hit rule below prefers the earlier
+    // of two equal distances).  A ray's discriminant is b^2 - a*c = a * (r^2 - d^2) with d the distance from the
+    // centre to the ray; in binary32 its sign is good to about 4e-7 * a * |camera - centre|^2, so a sphere can
+    // (seem to) be hit only by rays within sqrt(r^2 + 1e-5 * |camera - centre|^2) of its centre: spheres farther
+    // than that, plus a margin for the faces' own rounding, outside one of the four faces are left out.
+    float4 rec = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    bool keep = false;
     if (t < n) {
-      // staged per sphere: camera - centre and |camera - centre|^2 - radius^2, the same for every pixel
       const vkr_sphere& sp = p.spheres[base + t];
       const float oc[3] = {cam[0] - sp.center[0], cam[1] - sp.center[1], cam[2] - sp.center[2]};
-      s_sphere[t] = make_float4(oc[0], oc[1], oc[2], ((oc[0] * oc[0] + oc[1] * oc[1]) + oc[2] * oc[2]) - sp.radius * sp.radius);
+      const float oc2 = (oc[0] * oc[0] + oc[1] * oc[1]) + oc[2] * oc[2];
+      rec = make_float4(oc[0], oc[1], oc[2], oc2 - sp.radius * sp.radius);
+      const float reach = sqrtf(sp.radius * sp.radius + 1e-5f * oc2) + 1e-4f * sqrtf(oc2);
+      keep = true;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float outside = -((face[k][0] * oc[0] + face[k][1] * oc[1]) + face[k][2] * oc[2]);  // distance of the centre beyond face k
+        if (outside > reach) keep = false;  // false for NaN: kept
+      }
     }
+    const uint64_t kept = __ballot(keep);
+    const uint32_t wv = t >> 6;
+    if ((t & 63u) == 0u && wv < 2u) s_kept[wv] = (uint32_t)__popcll(kept);
     __syncthreads();
+    if (keep) {
+      const uint32_t at = (wv == 1u ? s_kept[0] : 0u) + __builtin_amdgcn_mbcnt_hi((uint32_t)(kept >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)kept, 0u));
+      s_sphere[at] = rec;
+      s_index[at] = base + t;
+    }
+    const uint32_t n_kept = s_kept[0] + s_kept[1];
+    __syncthreads();
+    if (n_kept == 0u) continue;
     float4 ahead = s_sphere[0];
-    for (uint32_t s = 0; s < n; ++s) {
+    for (uint32_t s = 0; s < n_kept; ++s) {
       const float4 sp = ahead;
-      ahead = s_sphere[min(s + 1u, n - 1u)];  // requested before this sphere's arithmetic
+      ahead = s_sphere[min(s + 1u, n_kept - 1u)];  // requested before this sphere's arithmetic
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float b = (sp.x * dir[i][0] + sp.y * dir[i][1]) + sp.z * dir[i][2];
@@ -218,7 +280,7 @@ __global__ __launch_bounds__(256) void gbuffer_fill_kernel(const FillParams p) {
           const float tt = (-b - sqrtf(disc)) / a[i];
           if (tt > 0.0f && tt < hit[i].t) {
             hit[i].t = tt;
-            hit[i].what = (int32_t)(base + s);
+            hit[i].what = (int32_t)s_index[s];
           }
         }
       }
