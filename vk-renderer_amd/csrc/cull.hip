@@ -240,6 +240,14 @@ __device__ __forceinline__ uint32_t mesh_holding(const CullParams& p, uint32_t i
 // placement launch.  One workgroup per block with the look-back straight after the tests measured 39-41 us (the
 // block idles through the round trips of its polls while holding its wave slots), the same with block numbers
 // drawn from a ticket counter 75 us (4096 returning atomics on one address serialise).
+// The launch is sensitive to how many workgroups are resident: capped at 512 / 768 / 1024 / 1280 of the 1536 that
+// 75 vector registers allow, a call takes 55 / 43.5 / 38.6 / 34.9 us against 32.4.  Getting to seven or eight
+// waves per SIMD was tried through the launch bound (72 registers: 5 spilled, 37.7 us; 64: 16 spilled, 43 us),
+// through 12-byte loads of the max corners (no fewer registers, the loads slower: 33.7 us) and by keeping the
+// per-lane segment bases in LDS (73 registers, one too many); scalar registers are the tighter resource (56
+// spilled into vector lanes, the six planes taking 24), and re-reading the planes per trip made the compiler
+// copy the argument block to scratch memory.
+
 constexpr uint32_t kKindAggregate = 1u, kKindPrefix = 2u;
 constexpr uint32_t kMaxPolls = 1u << 20;  // a predecessor that never publishes (it cannot, short of a fault) ends the wait
 
