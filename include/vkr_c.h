@@ -217,7 +217,11 @@ VKR_API int32_t vkr_prep_indirect(vkr_context* ctx, const vkr_cull_args* args);
  * All calls on one GPU share the one array: two calls whose kernels could overlap on a GPU (different
  * contexts, or threads of one process on the same device) race; calls on one context are stream-ordered and
  * safe.  The array keeps the previous call's words; each call tags its words with a sequence number of its
- * own, so nothing has to be cleared (the library zeroes the array when the numbers wrap, after 2^30 calls). */
+ * own, so nothing has to be cleared (the library zeroes the array when the numbers wrap, after 2^30 calls).
+ * Called while the context's stream (vkr_context_stream) is being captured into a HIP graph, the call records
+ * two nodes: a clear of the array and the launch, tagged with a number reserved for recorded launches - a
+ * replayed launch runs with the arguments it was recorded with and could not tell its own earlier words from
+ * new ones otherwise.  Replays may be mixed freely with ordinary calls. */
 #define VKR_NOALLOC_MAX_INSTANCES 4194304ull /* 2^22 */
 VKR_API int32_t vkr_prep_indirect_noalloc(vkr_context* ctx, const vkr_cull_args* args);
 

@@ -76,3 +76,61 @@ def test_rejects_sizes_beyond_the_static_array(vkr, synth, ctx):
     ctx.prep_indirect_noalloc(cs.args(scene["planes"], 0))
     ctx.wait_idle()
     assert cs.results()["error"] == 0
+
+
+def test_recorded_into_a_graph_and_replayed(vkr, synth, ctx):
+    """A caller under HIP stream capture is one of those this entry point is for.  A recorded launch runs again
+    with the arguments it was recorded with, so it cannot count on a fresh sequence number: the library notices
+    the capture, records a clear of the array in front of the launch and tags it with a number of its own.  The
+    graph is replayed four times over buffers whose boxes change between replays (words left by the replay before
+    would give wrong ranks), with an ordinary call on another scene in between, and must give the bytes of the
+    existing entry point every time."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    stream = C.c_void_p(ctx.stream())
+    scene = synth.cull_case(200000, 50, config_index=4)
+    other = synth.cull_case(30000, 11, config_index=9)
+    cs = vkr.CullScene(ctx, scene["aabb_min"], scene["aabb_max"], scene["mesh_base"], scene["cmd_template"])
+
+    def boxes(shift):
+        """The same segments with the boxes moved round by `shift` places (mesh ids stay where they are)."""
+        mn, mx = np.roll(scene["aabb_min"], shift, axis=0).copy(), np.roll(scene["aabb_max"], shift, axis=0).copy()
+        mn[:, 3] = scene["aabb_min"][:, 3]
+        return mn, mx
+
+    def expected(shift):
+        mn, mx = boxes(shift)
+        cs.aabb_min.upload(mn)
+        cs.aabb_max.upload(mx)
+        cs.visible.fill_u32(0xFFFFFFFF)  # slots past each mesh's count are written by neither call
+        ctx.prep_indirect(cs.args(scene["planes"], vkr.CULL_DETERMINISTIC))
+        ctx.wait_idle()
+        return cs.results()
+
+    shifts = (0, 777, 123456, 0)
+    wants = [expected(sh) for sh in shifts]
+    assert len({w["cmds"].tobytes() for w in wants[:3]}) == 3  # the replays really have different answers
+
+    graph, graph_exec = C.c_void_p(), C.c_void_p()
+    assert hip.hipStreamBeginCapture(stream, 1) == 0  # hipStreamCaptureModeThreadLocal
+    try:
+        ctx.prep_indirect_noalloc(cs.args(scene["planes"], 0))
+    finally:
+        assert hip.hipStreamEndCapture(stream, C.byref(graph)) == 0
+    assert hip.hipGraphInstantiate(C.byref(graph_exec), graph, None, None, C.c_size_t(0)) == 0
+    try:
+        for replay, shift in enumerate(shifts):
+            mn, mx = boxes(shift)
+            cs.aabb_min.upload(mn)
+            cs.aabb_max.upload(mx)
+            cs.visible.fill_u32(0xFFFFFFFF)
+            cs.cmd_out.fill_u32(0xDEADBEEF, 0, cs.m * 20 // 4 * 4)
+            ctx.wait_idle()
+            assert hip.hipGraphLaunch(graph_exec, stream) == 0
+            ctx.wait_idle()
+            _same(wants[replay], cs.results())
+            if replay == 1:  # an ordinary call in between leaves its own words in the array
+                _same(*_both(vkr, ctx, other, other["planes"]))
+    finally:
+        hip.hipGraphExecDestroy(graph_exec)
+        hip.hipGraphDestroy(graph)

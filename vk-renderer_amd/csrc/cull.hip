@@ -544,7 +544,7 @@ void* vkr_cull_static_state(int device, uint64_t* out_bytes, uint32_t* out_seq, 
   std::lock_guard<std::mutex> lock(g_scratch_mutex);
   StaticState& st = g_scratch[device];
   if (!st.ptr) return nullptr;
-  const bool wrap = st.seq + 1u >= kCullSeqEnd;
+  const bool wrap = st.seq + 1u >= kCullSeqRecorded;
   st.seq = wrap ? 1u : st.seq + 1u;
   if (out_seq) *out_seq = st.seq;
   if (out_clear_first) *out_clear_first = wrap;

@@ -253,6 +253,14 @@ int32_t run_cull(vkr_context* ctx, const vkr_cull_args* a, bool static_state = f
     void* state = vkr_cull_static_state(ctx->device, &bytes, &seq, &clear_first);
     if (!state) return fail(VKR_ERR_BAD_STATE, "vkr_prep_indirect_noalloc: the static state of device %d was not resolved at context creation", ctx->device);
     if (need > bytes) return fail(VKR_ERR_INVALID_ARGUMENT, "static state too small for %llu instances", (unsigned long long)a->instance_count);
+    // Under stream capture the launch becomes a graph node that runs again, unchanged, at every replay: it gets
+    // the sequence number reserved for recorded launches and a clear of the array in front of it (also recorded).
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    VKR_HIP(hipStreamIsCapturing(ctx->stream, &capture));
+    if (capture != hipStreamCaptureStatusNone) {
+      seq = kCullSeqRecorded;
+      clear_first = true;
+    }
     if (clear_first) VKR_HIP(hipMemsetAsync(state, 0, bytes, ctx->stream));
     VKR_HIP(vkr_launch_cull_deterministic(p, state, seq, resident, ctx->stream));
   } else if (a->flags & VKR_CULL_DETERMINISTIC) {
@@ -265,7 +273,7 @@ int32_t run_cull(vkr_context* ctx, const vkr_cull_args* a, bool static_state = f
       ctx->cull_state_bytes = need;
       ctx->cull_seq = 0;
     }
-    if (ctx->cull_state && (ctx->cull_seq == 0u || ctx->cull_seq + 1u >= kCullSeqEnd)) {  // fresh memory, or every sequence number has been used
+    if (ctx->cull_state && (ctx->cull_seq == 0u || ctx->cull_seq + 1u >= kCullSeqRecorded)) {  // fresh memory, or every sequence number has been used
       VKR_HIP(hipMemsetAsync(ctx->cull_state, 0, ctx->cull_state_bytes, ctx->stream));
       ctx->cull_seq = 0;
     }

@@ -102,6 +102,10 @@ struct OnePassState {
   uint32_t seq;
 };
 constexpr uint32_t kCullSeqEnd = 1u << 30;
+// A launch recorded into a HIP graph runs again with the arguments it was recorded with, sequence number
+// included, so it cannot rely on "different from every earlier call": recorded launches all use this number,
+// which the counters never hand out, and are preceded by a recorded clear of the state.
+constexpr uint32_t kCullSeqRecorded = kCullSeqEnd - 1u;
 uint64_t vkr_cull_state_bytes(uint64_t instance_count);
 uint32_t vkr_cull_blocks_per_cu();
 hipError_t vkr_launch_cull_atomic(const CullParams& p, hipStream_t stream);
