@@ -134,3 +134,61 @@ def test_recorded_into_a_graph_and_replayed(vkr, synth, ctx):
     finally:
         hip.hipGraphExecDestroy(graph_exec)
         hip.hipGraphDestroy(graph)
+
+
+def test_stateful_calls_refuse_to_be_recorded(vkr, synth, ctx):
+    """The deterministic cull with context-owned state and the radius-cutoff resolve pass a value to their kernels
+    that the host advances per call: recorded, they would replay with a stale one, so they say no.  The plain
+    resolve and the atomic cull carry no such state and record fine (their replay is checked against a direct call)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    stream = C.c_void_p(ctx.stream())
+    scene = synth.cull_case(20000, 8, config_index=3)
+    cs = vkr.CullScene(ctx, scene["aabb_min"], scene["aabb_max"], scene["mesh_base"], scene["cmd_template"])
+    case = synth.deferred_case(64, 36, 13, config_index=0)
+    gb = vkr.GBuffer(ctx, 64, 36).upload(case["gbuf"])
+    lights = ctx.buffer_from(case["lights"])
+    out = ctx.image(vkr.FORMAT_R8G8B8A8_UNORM, 64, 36)
+    plain = vkr.make_deferred_args(gb, out, lights, 13, case["push"])
+    push = case["push"].copy()
+    push[3] = 50.0
+    cutoff = vkr.make_deferred_args(gb, out, lights, 13, push, flags=vkr.DEFERRED_RADIUS_CUTOFF)
+    ctx.deferred_resolve(plain)
+    cs.visible.fill_u32(0xFFFFFFFF)
+    ctx.prep_indirect(cs.args(scene["planes"], 0))
+    ctx.wait_idle()
+    want_img, want_cull = out.download(np.uint8, 4), cs.results()
+
+    graph, graph_exec = C.c_void_p(), C.c_void_p()
+    assert hip.hipStreamBeginCapture(stream, 1) == 0
+    try:
+        with pytest.raises(vkr.VkrError, match="cannot be recorded"):
+            ctx.prep_indirect(cs.args(scene["planes"], vkr.CULL_DETERMINISTIC))
+        with pytest.raises(vkr.VkrError, match="cannot be recorded"):
+            ctx.deferred_resolve(cutoff)
+        ctx.deferred_resolve(plain)
+        ctx.prep_indirect(cs.args(scene["planes"], 0))
+    finally:
+        assert hip.hipStreamEndCapture(stream, C.byref(graph)) == 0
+    assert hip.hipGraphInstantiate(C.byref(graph_exec), graph, None, None, C.c_size_t(0)) == 0
+    try:
+        for _ in range(2):
+            out.buffer.fill_u32(0)
+            cs.visible.fill_u32(0xFFFFFFFF)
+            cs.cmd_out.fill_u32(0xDEADBEEF, 0, cs.m * 20 // 4 * 4)
+            ctx.wait_idle()
+            assert hip.hipGraphLaunch(graph_exec, stream) == 0
+            ctx.wait_idle()
+            assert np.array_equal(out.download(np.uint8, 4), want_img)
+            got = cs.results()
+            assert got["cmds"].tobytes() == want_cull["cmds"].tobytes()
+            counts = got["cmds"]["instanceCount"]
+            for b, c in zip(scene["mesh_base"], counts):
+                assert np.array_equal(np.sort(got["visible"][int(b):int(b) + int(c)]), np.sort(want_cull["visible"][int(b):int(b) + int(c)]))
+    finally:
+        hip.hipGraphExecDestroy(graph_exec)
+        hip.hipGraphDestroy(graph)
+    # outside capture everything works as before
+    ctx.deferred_resolve(cutoff)
+    ctx.prep_indirect(cs.args(scene["planes"], vkr.CULL_DETERMINISTIC))
+    ctx.wait_idle()

@@ -130,6 +130,13 @@ int32_t check_image(const vkr_image2d& im, const char* what, uint32_t want_a, ui
   return VKR_OK;
 }
 
+// A launch recorded into a HIP graph runs again with its recorded arguments; calls whose kernels take a value
+// that the host advances per call (queue parity, sequence number) refuse to be recorded.
+bool stream_is_recording(vkr_context* ctx) {
+  hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(ctx->stream, &capture) == hipSuccess && capture != hipStreamCaptureStatusNone;
+}
+
 int32_t run_deferred(vkr_context* ctx, const vkr_deferred_args* a) {
   if (!ctx || !a) return fail(VKR_ERR_INVALID_ARGUMENT, "vkr_deferred_resolve: null argument");
   const uint32_t w = a->out.width, h = a->out.height;
@@ -191,6 +198,8 @@ int32_t run_deferred(vkr_context* ctx, const vkr_deferred_args* a) {
   VKR_HIP(hipSetDevice(ctx->device));
   const TiledLayout layout = vkr_deferred_tiled_layout(p);
   if (layout.tiled) {
+    if (stream_is_recording(ctx))
+      return fail(VKR_ERR_BAD_STATE, "the radius-cutoff resolve keeps per-call state on the host and cannot be recorded into a HIP graph");
     if (!ctx->tile_counters) {
       VKR_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->tile_counters), 256));
       VKR_HIP(hipMemsetAsync(ctx->tile_counters, 0, 256, ctx->stream));
@@ -264,6 +273,8 @@ int32_t run_cull(vkr_context* ctx, const vkr_cull_args* a, bool static_state = f
     if (clear_first) VKR_HIP(hipMemsetAsync(state, 0, bytes, ctx->stream));
     VKR_HIP(vkr_launch_cull_deterministic(p, state, seq, resident, ctx->stream));
   } else if (a->flags & VKR_CULL_DETERMINISTIC) {
+    if (stream_is_recording(ctx))
+      return fail(VKR_ERR_BAD_STATE, "the deterministic cull keeps per-call state on the host and cannot be recorded into a HIP graph: use vkr_prep_indirect_noalloc");
     if (need > ctx->cull_state_bytes) {
       // hipFree waits for the device: an earlier launch still using the old state finishes first
       if (ctx->cull_state) VKR_HIP(hipFree(ctx->cull_state));
