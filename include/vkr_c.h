@@ -117,7 +117,9 @@ typedef struct vkr_image2d {
                                          the tiles no light reaches straight away (their pixels are their ambient term)
                                          and shades the others from their lists.  Lists, bins and the queue of lit tiles
                                          live in context-owned device memory (1 KiB + 8 bytes per tile, 4 bytes per bin
-                                         and light; allocated or grown inside the call, released with the context). */
+                                         and light; allocated or grown inside the call, released with the context).
+                                         VKR_ERR_BAD_STATE while the context's stream is being captured into a HIP
+                                         graph: the launches take a value the host advances per call. */
 #define VKR_DEFERRED_NO_TILE_LISTS 2u /* with RADIUS_CUTOFF: apply the cutoff per pixel only and loop over the whole
                                          light table (diagnostic; results are bit-identical to the tiled path) */
 #define VKR_DEFERRED_WHOLE_TILE_WORKGROUPS 4u /* whole-table loop: always one 256-thread workgroup per 32 x 32 pixel
@@ -176,8 +178,10 @@ typedef struct vkr_draw_indexed_indirect_command {
 
 #define VKR_CULL_DETERMINISTIC 1u /* visible[] ascending inside each mesh segment (one launch; its state, one 64-bit word
                                      per 1024 instances, lives in context-owned device memory that is allocated or grown
-                                     inside the call and released with the context); default is one atomic per wave and
-                                     mesh run (segment order unspecified) */
+                                     inside the call and released with the context; VKR_ERR_BAD_STATE while the
+                                     context's stream is being captured into a HIP graph - vkr_prep_indirect_noalloc
+                                     is the form that records); default is one atomic per wave and mesh run (segment
+                                     order unspecified) */
 
 /* The pass /root/reference/shaders/prep_indirect.comp:1-5 leaves empty.  Instance i carries a
  * world-space AABB and a mesh id; instances of a mesh are contiguous, as the model-matrix array of
