@@ -213,3 +213,28 @@ def test_argument_errors(vkr, synth, ctx):
     ctx.prep_indirect(a)
     ctx.wait_idle()
     assert int(cs.cmd_out.download(vkr.DRAW_CMD_DTYPE, 4)["instanceCount"].sum()) == 0
+
+
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_subnormal_distances_keep_their_sign(vkr, synth, oracle, ctx, deterministic):
+    """Plane distances that are subnormal numbers: a device that flushed them to zero would call a box visible
+    (-0 >= 0) that the binary32 evaluation on the CPU culls.  Boxes a few 1e-39 either side of a plane through
+    the origin, products and sums all in the subnormal range."""
+    n, m = 4096, 4
+    scene = synth.cull_case(n, m, config_index=12)
+    rng = np.random.default_rng(12)
+    mn = scene["aabb_min"].copy()
+    mx = scene["aabb_max"].copy()
+    tiny = (rng.integers(-2000, 2000, (n, 3)).astype(np.float64) * 1e-42).astype(np.float32)  # multiples of the smallest subnormal
+    mn[:, :3] = tiny
+    mx[:, :3] = tiny + np.float32(3e-42)
+    scene["aabb_min"], scene["aabb_max"] = mn, mx
+    planes = np.zeros((6, 4), np.float32)
+    planes[:, 3] = 1.0
+    planes[0] = [1.0, 0.0, 0.0, -1e-39]    # x >= 1e-39 at the p-vertex
+    planes[1] = [0.0, -0.5, 0.0, 2e-40]    # -0.5 y + 2e-40 >= 0
+    planes[2] = [0.25, 0.25, 0.25, 0.0]
+    ref = oracle.cull(mn, mx, planes, scene["mesh_base"], scene["cmd_template"])
+    assert 0.02 < ref["mask"].mean() < 0.98  # the planes really split the set
+    res, _ = _run(vkr, ctx, scene, planes, vkr.CULL_DETERMINISTIC if deterministic else 0)
+    _compare(res, ref, scene, deterministic)
