@@ -3,8 +3,10 @@
 Only tests/, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
 ``bench.py`` may import this package; the product path never does.
 
-PARITY UNPINNED: the reference has no tests/golden vectors for either pass and
-its shaders cannot be executed here (see the headers of deferred_oracle.c and
+The reference has no tests/golden vectors for either pass and no Vulkan driver can
+run its shaders here.  The deferred restatement is pinned against the TEXT of the
+reference's shader, evaluated by tests/glsl_eval.py (see deferred_oracle.c); the
+cull is PARITY UNPINNED by nature - the reference's shader for it is empty (see
 cull_oracle.c).  The C sources restate /root/reference/shaders/deferred.comp and
 the data contract of /root/reference/src/vkmodel.cpp; this module is the ctypes
 binding plus a numpy restatement of the glm host math the reference's caller

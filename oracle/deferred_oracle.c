@@ -3,11 +3,16 @@
  * resolve.  Nothing under oracle/ is part of the shipped path; only tests, the
  * smoke check and the benchmark's CPU-baseline leg may load this library.
  *
- * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for
- * this pass, and its shader cannot be executed in this environment (no Vulkan
- * loader/ICD, no GLSL compiler).  This file is a statement-by-statement
- * restatement of /root/reference/shaders/deferred.comp:1-131 and is pinned only
- * by the known-answer cases in tests/.
+ * PINNED AGAINST THE SHADER'S TEXT, NOT AGAINST A VULKAN DRIVER: the reference
+ * ships no tests, golden vectors or fixtures for this pass, and its shader
+ * cannot be executed by a driver in this environment (no Vulkan loader/ICD, no
+ * GLSL compiler).  This file is a statement-by-statement restatement of
+ * /root/reference/shaders/deferred.comp:1-131.  What pins it: the reference's
+ * own text, evaluated per pixel in binary64 by tests/glsl_eval.py (a small
+ * GLSL-subset evaluator; tests/test_shader_text_cpu.py and the fixture
+ * tests/golden/shader_text_eval_*.npz made from such a run) - oracle_deferred_f64
+ * agrees with it to 1e-12 - besides the known-answer cases in tests/.  How a
+ * driver rounds pow / normalize / division remains outside any pin.
  *
  * Three evaluations of the same algorithm are built from one body
  * (deferred_oracle_body.inc):

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Runs the reference's deferred shader - its own text, /root/reference/shaders/deferred.comp, read at run time and
+evaluated by tests/glsl_eval.py in binary64 - on a small seeded frame and stores inputs and result:
+
+    python tests/golden/make_shader_eval.py      ->  tests/golden/shader_text_eval_24x10_L13.npz
+
+The fixture is data (inputs and the colours the shader's text produces); none of the shader's text is stored.  The
+frame keeps every light some way off every surface, so that the result does not hinge on the last bit of a
+reconstructed position and the binary32 paths can be held to the usual 1e-4."""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+SHADER = "/root/reference/shaders/deferred.comp"
+W, H, L = 24, 10, 13
+OUT = os.path.join(HERE, f"shader_text_eval_{W}x{H}_L{L}.npz")
+
+
+def make_case():
+    synth = importlib.import_module("vk-renderer_amd.synth")
+    case = synth.deferred_case(W, H, L, config_index=21)
+    lights = case["lights"].copy()
+    # move the lights towards the camera until none is nearer than 25 units to any pixel's surface point
+    P = synth.unproject(case["camera"]["inv_vp"], W, H, case["gbuf"]["depth"]).reshape(-1, 3)
+    cam = np.asarray(case["camera"]["pos"], np.float64)
+    for i in range(L):
+        p = lights[i, 0:3].astype(np.float64)
+        for _ in range(200):
+            if np.sqrt(((P - p) ** 2).sum(-1)).min() >= 25.0:
+                break
+            p = p + (cam - p) * 0.05
+        lights[i, 0:3] = p.astype(np.float32)
+    case["lights"] = lights
+    return case
+
+
+def main():
+    from glsl_eval import run_deferred_shader
+    case = make_case()
+    out = run_deferred_shader(open(SHADER).read(), case["gbuf"], case["lights"], case["push"], W, H)
+    np.savez_compressed(OUT, albedo=case["gbuf"]["albedo"], material=case["gbuf"]["material"], normal=case["gbuf"]["normal"],
+                        depth=case["gbuf"]["depth"], lights=case["lights"], push=case["push"], color=out)
+    print(OUT, out.shape, float(out[..., :3].mean()))
+
+
+if __name__ == "__main__":
+    main()

@@ -122,6 +122,27 @@ def test_zero_lights_is_ambient(vkr, synth, ctx):
     np.testing.assert_allclose(got[..., :3], amb, rtol=3e-7, atol=0)
 
 
+def test_kernels_against_the_shader_text_fixture(vkr, ctx):
+    """tests/golden/shader_text_eval_24x10_L13.npz holds a frame and the colours that the reference's shader - its
+    own text, evaluated in binary64 by tests/glsl_eval.py (tests/golden/make_shader_eval.py) - gives for it.  The
+    float outputs within 1e-4 of them, the 8-bit outputs within one step of their quantisation, both workgroup
+    shapes."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "shader_text_eval_24x10_L13.npz"))
+    case = {"width": 24, "height": 10, "gbuf": {k: z[k] for k in ("albedo", "material", "normal", "depth")}, "lights": z["lights"], "push": z["push"]}
+    want = z["color"][..., :3]
+    for flags in (0, vkr.DEFERRED_WHOLE_TILE_WORKGROUPS):
+        got, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT, flags=flags)
+        assert_color_close(got[..., :3], want, what="rgba32f against the shader text")
+        assert (got[..., 3] == 1.0).all()
+        half, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R16G16B16A16_SFLOAT, flags=flags)
+        assert np.abs(half[..., :3].astype(np.float64) - want).max() <= 1e-3 * want.max()
+        q = np.rint(np.clip(want, 0, 1) * 255)
+        for fmt, order in ((vkr.FORMAT_R8G8B8A8_UNORM, (0, 1, 2)), (vkr.FORMAT_B8G8R8A8_UNORM, (2, 1, 0))):
+            got8, _ = run_deferred_gpu(vkr, ctx, case, fmt, flags=flags)
+            assert np.abs(got8[..., list(order)].astype(np.float64) - q).max() <= 1 and (got8[..., 3] == 255).all()
+
+
 def test_band_rows_match_full_frame(vkr, synth, ctx):
     """Screen-band sharding: shading rows [a,b) alone gives the same bytes as the full dispatch."""
     case = synth.deferred_case(96, 70, 32, config_index=2)

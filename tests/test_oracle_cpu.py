@@ -1,9 +1,9 @@
 """CPU checks of the oracle itself: closed-form known-answer cases for the BRDF pieces of
 /root/reference/shaders/deferred.comp, the cull rule, and the committed golden vectors.
 
-The reference has no tests or fixtures (parity unpinned), so the oracle is pinned by (a) analytic
-answers worked out by hand from the shader's formulas and (b) its own committed outputs, which guard
-against drift."""
+The reference has no tests or fixtures, so the oracle is pinned by (a) analytic answers worked out by
+hand from the shader's formulas, (b) its own committed outputs, which guard against drift, and (c) in
+test_shader_text_cpu.py, the reference's shader text evaluated on the CPU."""
 import hashlib
 import json
 import os

@@ -1,0 +1,77 @@
+"""The reference's shader text, run: tests/glsl_eval.py evaluates shaders/deferred.comp itself (read from
+/root/reference where that exists - this container; the GPU box has no copy) per pixel in binary64, and the CPU
+restatement in oracle/ must give the same colours.  The committed fixture tests/golden/shader_text_eval_*.npz holds
+the inputs and the result of such a run (tests/golden/make_shader_eval.py), so the comparison also runs where the
+reference is absent, and the GPU parity tests compare the kernels with it."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from glsl_eval import GlslError, Interpreter, run_deferred_shader
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SHADER = "/root/reference/shaders/deferred.comp"
+FIXTURE = os.path.join(HERE, "golden", "shader_text_eval_24x10_L13.npz")
+
+
+def _fixture():
+    d = np.load(FIXTURE)
+    gbuf = {k: d[k] for k in ("albedo", "material", "normal", "depth")}
+    return gbuf, d["lights"], d["push"], d["color"]
+
+
+def test_evaluator_on_known_snippets():
+    src = """
+    #define N 3
+    float sq(float x) { return x * x; }
+    float pick(float x) { return x > 0 ? 1 : 0; }
+    vec3 f(vec3 a, float t) {
+        float s = 0.0;
+        for (int i = 0; i < N; i++) { s += sq(a[i]); }
+        if (s <= 1e-6) return vec3(0.0);
+        vec3 h = normalize(a);
+        s *= mix(1.0, 1.0/1.51, t);
+        return h * s + vec3(pick(t), 2, max(1 - t, 0));
+    }
+    """
+    it = Interpreter(src, {}, {})
+    a = np.array([1.0, 2.0, 2.0])
+    got = it.call("f", [a, 0.5])
+    k = float(np.float32(1.0) / np.float32(1.51))  # folded in binary32
+    want = a / 3.0 * (9.0 * (1.0 * 0.5 + k * 0.5)) + np.array([1.0, 2.0, 0.5])
+    assert np.allclose(got, want, rtol=1e-15, atol=0)
+    assert np.array_equal(it.call("f", [np.zeros(3), 0.5]), np.zeros(3))
+    with pytest.raises(GlslError):
+        Interpreter("float g(float x) { while (x > 0) x -= 1; return x; }", {}, {}).call("g", [1.0])
+
+
+def test_oracle_equals_the_shader_text_on_the_fixture(oracle):
+    """binary64 against binary64: the restatement and the text agree to rounding noise on every pixel."""
+    gbuf, lights, push, color = _fixture()
+    got = oracle.deferred(gbuf, lights, push, mode="f64", want=("f64",))
+    assert not got["near_threshold"].any()
+    a, b = got["f64"][..., :3], color[..., :3]
+    assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max() + 1e-15, float(np.abs(a - b).max())
+    assert (color[..., 3] == 1.0).all() and b.max() > 10 * b.min() > 0  # lit and unlit pixels both present
+    # the binary32 restatement, the one the CPU baseline times, within the tolerance the kernels are held to
+    o32 = oracle.deferred(gbuf, lights, push, mode="f32", want=("f32",))["f32"][..., :3].astype(np.float64)
+    assert (np.abs(o32 - b) <= 1e-4 * np.abs(b) + 2e-6).all()
+
+
+@pytest.mark.skipif(not os.path.exists(SHADER), reason="reference sources not present")
+def test_fixture_is_what_the_shader_text_gives_today():
+    """Re-runs the reference's text on the fixture's inputs: the stored colours are its output, bit for bit; and on
+    a second frame (other seed, lights closer in) the restatement agrees with it as well."""
+    gbuf, lights, push, color = _fixture()
+    text = open(SHADER).read()
+    assert np.array_equal(run_deferred_shader(text, gbuf, lights, push, 24, 10), color)
+    synth = importlib.import_module("vk-renderer_amd.synth")
+    oracle = importlib.import_module("oracle")
+    case = synth.deferred_case(9, 7, 13, config_index=33)
+    mine = run_deferred_shader(text, case["gbuf"], case["lights"], case["push"], 9, 7)
+    theirs = oracle.deferred(case["gbuf"], case["lights"], case["push"], mode="f64", want=("f64",))
+    ok = theirs["near_threshold"] == 0  # a light exactly at the 1e-6 early-out may fall either way
+    a, b = theirs["f64"][..., :3][ok], mine[..., :3][ok]
+    assert ok.mean() > 0.9 and np.abs(a - b).max() <= 1e-11 * np.abs(b).max() + 1e-15
