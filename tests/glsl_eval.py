@@ -2,7 +2,7 @@
 deferred pass uses, so that the SHADER'S OWN TEXT can be run on the CPU (per invocation, in binary64) and its result
 compared with the CPU restatement in oracle/.  Nothing under vk-renderer_amd/ uses it.
 
-Supported: object-like #define; functions with float / int / vecN / void types; declarations, assignments and
+Supported: object-like #define; functions with float / int / vecN / matN / void types; declarations, assignments and
 compound assignments; if / else, for, return; ?:, ||, &&, comparisons, + - * /, unary - and !, postfix ++; calls,
 constructors (vec2/3/4, ivec2, float, int), swizzles, member access and indexing on host-supplied objects; the
 builtins listed in BUILTINS.  Floating literals are binary32 values (GLSL's float), an operation whose operands are
@@ -24,7 +24,7 @@ class Const(float):
 
 
 TOKEN = re.compile(r"\s*(?:(\d+\.\d*(?:[eE][-+]?\d+)?[fF]?|\.\d+(?:[eE][-+]?\d+)?[fF]?|\d+[eE][-+]?\d+[fF]?)|(\d+)|([A-Za-z_]\w*)|(\+\+|--|<=|>=|==|!=|&&|\|\||[-+*/]=|[-+*/<>=!?:;,.(){}\[\]]))")
-TYPES = {"float", "int", "uint", "bool", "vec2", "vec3", "vec4", "ivec2", "ivec3", "uvec2", "uvec3", "mat4", "void"}
+TYPES = {"float", "int", "uint", "bool", "vec2", "vec3", "vec4", "ivec2", "ivec3", "uvec2", "uvec3", "mat3", "mat4", "void"}
 SWIZZLE = {c: i for i, c in enumerate("xyzw")} | {c: i for i, c in enumerate("rgba")}
 
 
@@ -264,7 +264,14 @@ def _length(v):
     return float(np.sqrt(np.dot(v, v)))
 
 
+def _mat3(*cols):
+    if len(cols) != 3 or any(np.size(c) != 3 for c in cols):
+        raise GlslError("mat3 is built from three vec3 columns in the subset")
+    return np.stack([np.asarray(c, np.float64) for c in cols], axis=1)  # [row][column]
+
+
 BUILTINS = {
+    "mat3": _mat3, "nonuniformEXT": lambda x: x,
     "vec2": _ctor(2), "vec3": _ctor(3), "vec4": _ctor(4), "ivec2": lambda *a: _ctor(2)(*a).astype(np.int64),
     "float": lambda x: float(x), "int": lambda x: int(x),
     "dot": lambda a, b: float(np.dot(a, b)), "length": _length, "normalize": lambda v: np.asarray(v) / _length(v),
@@ -335,6 +342,9 @@ class Interpreter:
                         rhs = self.arith(node[2][0], cur, rhs)
                     s[node[1]] = float(rhs) if isinstance(rhs, Const) else rhs
                     return
+            if node[1] in self.globals and node[2] == "=":  # an `out` variable or a built-in output
+                self.globals[node[1]] = float(rhs) if isinstance(rhs, Const) else rhs
+                return
             raise GlslError(f"assignment to unknown variable {node[1]}")
         elif kind == "if":
             if self.eval(node[1], scopes):
@@ -362,8 +372,8 @@ class Interpreter:
                 raise GlslError("integer division is outside the subset")
             return {"+": a + b, "-": a - b, "*": a * b}[op]
         x, y = (a, b)
-        if op == "*" and np.ndim(x) == 2 and np.ndim(y) == 1:
-            r = x @ y  # mat4 * vec4
+        if op == "*" and np.ndim(x) == 2 and np.ndim(y) in (1, 2):
+            r = x @ y  # matrix * vector, matrix * matrix
         else:
             r = {"+": lambda: x + y, "-": lambda: x - y, "*": lambda: x * y, "/": lambda: x / y}[op]() if not (np.ndim(x) == 0 and np.ndim(y) == 0) else \
                 {"+": lambda: float(x) + float(y), "-": lambda: float(x) - float(y), "*": lambda: float(x) * float(y), "/": lambda: float(x) / float(y)}[op]()
@@ -450,4 +460,36 @@ def run_deferred_shader(source: str, gbuf: dict, lights: np.ndarray, push: np.nd
         for x in range(width):
             g["gl_GlobalInvocationID"] = np.array([x, y, 0], np.float64)
             interp.call("main", [])
+    return out
+
+
+def run_offscreen_shaders(vert_source: str, frag_source: str, normal_obj, tangent_obj, matrices, matrix_index, albedo_texel, specular_texel,
+                          normal_texel) -> dict:
+    """The reference's G-buffer pass for one surface sample per pixel: its vertex shader's main() with the pixel's
+    own attributes (object-space normal / tangent, model matrix index), then its fragment shader's main() with the
+    frame that came out and the pixel's three texels.  Inputs (H,W,3|4) / (H,W) / (K,16 column-major); returns the
+    three colour outputs as (H,W,4) binary64."""
+    H, W = matrix_index.shape
+    mats = [np.asarray(m, np.float64).reshape(4, 4).T for m in np.asarray(matrices).reshape(-1, 16)]  # [row][column]
+    out = {k: np.zeros((H, W, 4), np.float64) for k in ("outColor", "outSpecular", "outNormal")}
+    vg = {"push": {"vp": np.eye(4)}, "gl_DrawID": 0, "gl_InstanceIndex": 0, "gl_Position": None,
+          "ubo0": {"modelData": [{"matIdx": 0, "modelMatrixBaseIndex": 0}]}, "ubo1": {"modelMatrices": mats},
+          "inPos": np.zeros(3), "inUV": np.zeros(3), "outUV": None, "outTexOffset": None, "outTBN": None}
+    vert = Interpreter(vert_source, vg, {})
+    texels = {}
+    fg = {"samplers": [0, 1, 2], "inUV": np.zeros(2), "inTexOffset": 0, "inTBN": None, "outColor": None, "outSpecular": None, "outNormal": None}
+    frag = Interpreter(frag_source, fg, {"texture": lambda sampler, uv: texels[int(sampler)].copy()})
+    for y in range(H):
+        for x in range(W):
+            vg["ubo0"]["modelData"][0]["modelMatrixBaseIndex"] = int(matrix_index[y, x])
+            vg["inNormal"] = np.asarray(normal_obj[y, x, :3], np.float64)
+            vg["inTangent"] = np.asarray(tangent_obj[y, x, :3], np.float64)
+            vert.call("main", [])
+            fg["inTBN"] = vg["outTBN"]
+            fg["inTexOffset"] = vg["outTexOffset"]
+            texels.update({0: np.asarray(albedo_texel[y, x], np.float64), 1: np.asarray(normal_texel[y, x], np.float64),
+                           2: np.asarray(specular_texel[y, x], np.float64)})
+            frag.call("main", [])
+            for k in out:
+                out[k][y, x] = fg[k]
     return out

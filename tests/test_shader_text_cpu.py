@@ -75,3 +75,34 @@ def test_fixture_is_what_the_shader_text_gives_today():
     ok = theirs["near_threshold"] == 0  # a light exactly at the 1e-6 early-out may fall either way
     a, b = theirs["f64"][..., :3][ok], mine[..., :3][ok]
     assert ok.mean() > 0.9 and np.abs(a - b).max() <= 1e-11 * np.abs(b).max() + 1e-15
+
+
+VERT, FRAG = "/root/reference/shaders/offscreen.vert", "/root/reference/shaders/offscreen.frag"
+
+
+@pytest.mark.skipif(not (os.path.exists(VERT) and os.path.exists(FRAG)), reason="reference sources not present")
+def test_surface_encode_oracle_equals_the_offscreen_shaders_text(oracle):
+    """The G-buffer pass's two shaders, their own text, per pixel (vertex stage with the pixel's attributes, then the
+    fragment stage) against oracle_gbuffer_encode_surfaces: the attachment values agree to the last step of their
+    formats (the text runs in binary64, the restatement in binary32, so a value on a rounding boundary may land
+    one step apart)."""
+    from glsl_eval import run_offscreen_shaders
+    rng = np.random.default_rng(41)
+    h, w, K = 6, 16, 5
+    normal_obj = rng.normal(size=(h, w, 4)).astype(np.float32)
+    tangent_obj = rng.normal(size=(h, w, 4)).astype(np.float32)
+    index = rng.integers(0, K, (h, w)).astype(np.uint32)
+    normal_obj[..., 3] = index.view(np.float32)
+    matrices = (rng.normal(size=(K, 16)) * np.exp(rng.uniform(-2, 2, (K, 1)))).astype(np.float32)
+    albedo = rng.uniform(0, 1, (h, w, 4)).astype(np.float32)
+    specular = rng.uniform(0, 1, (h, w, 4)).astype(np.float32)
+    normal_texel = rng.uniform(0, 1, (h, w, 4)).astype(np.float32)
+    text = run_offscreen_shaders(open(VERT).read(), open(FRAG).read(), normal_obj, tangent_obj, matrices, index, albedo, specular, normal_texel)
+    mine = oracle.gbuffer_encode_surfaces(albedo, specular, normal_texel, normal_obj, tangent_obj, np.zeros((h, w), np.float32), matrices)
+    # rgba16f normal: within one half-precision step; w = 1
+    n_text, n_mine = text["outNormal"], mine["normal"].astype(np.float64)
+    step = np.maximum(np.abs(n_text), 2.0 ** -14) * 2.0 ** -10
+    assert (np.abs(n_text - n_mine) <= step).all() and (n_mine[..., 3] == 1.0).all()
+    # rgba8 colour and material: within one step of 1/255
+    for name, key in (("outColor", "albedo"), ("outSpecular", "material")):
+        assert np.abs(np.rint(np.clip(text[name], 0, 1) * 255) - mine[key].astype(np.float64)).max() <= 1, name
