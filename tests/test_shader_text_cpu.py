@@ -106,3 +106,21 @@ def test_surface_encode_oracle_equals_the_offscreen_shaders_text(oracle):
     # rgba8 colour and material: within one step of 1/255
     for name, key in (("outColor", "albedo"), ("outSpecular", "material")):
         assert np.abs(np.rint(np.clip(text[name], 0, 1) * 255) - mine[key].astype(np.float64)).max() <= 1, name
+
+
+@pytest.mark.skipif(not os.path.exists(SHADER), reason="reference sources not present")
+def test_shader_text_on_the_13_light_golden_frame(oracle):
+    """The committed 64 x 36 frame with the reference's own light count (tests/golden/deferred_64x36_L13.npz, whose
+    stored outputs are the oracle's): the shader's text against the binary64 restatement on all 2304 pixels, and
+    against the stored mixed-precision colours where the position's last bit does not matter (1e-4)."""
+    z = np.load(os.path.join(HERE, "golden", "deferred_64x36_L13.npz"))
+    gbuf = {k: z[k] for k in ("albedo", "material", "normal", "depth")}
+    text = run_deferred_shader(open(SHADER).read(), gbuf, z["lights"], z["push"], 64, 36)[..., :3]
+    o64 = oracle.deferred(gbuf, z["lights"], z["push"], mode="f64", want=("f64",))
+    ok = o64["near_threshold"] == 0
+    assert ok.mean() > 0.95
+    a = o64["f64"][..., :3]
+    assert np.abs(a - text)[ok].max() <= 1e-11 * np.abs(text).max() + 1e-15
+    stored = z["out_mix_f64"][..., :3]
+    close = np.abs(stored - text) <= 1e-4 * np.abs(text) + 2e-6
+    assert close[ok & (z["near_threshold"] == 0)].mean() > 0.995
