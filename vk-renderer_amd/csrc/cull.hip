@@ -245,8 +245,8 @@ __device__ __forceinline__ uint32_t mesh_holding(const CullParams& p, uint32_t i
 // waves per SIMD was tried through the launch bound (72 registers: 5 spilled, 37.7 us; 64: 16 spilled, 43 us),
 // through 12-byte loads of the max corners (no fewer registers, the loads slower: 33.7 us) and by keeping the
 // per-lane segment bases in LDS (73 registers, one too many); scalar registers are the tighter resource (56
-// spilled into vector lanes, the six planes taking 24), and re-reading the planes per trip made the compiler
-// copy the argument block to scratch memory.
+// spilled into vector lanes, the six planes taking 24): re-reading the planes from the argument block per trip
+// made the compiler copy the block to scratch memory, and fetching them from LDS per trip raised the count to 79.
 
 constexpr uint32_t kKindAggregate = 1u, kKindPrefix = 2u;
 constexpr uint32_t kMaxPolls = 1u << 20;  // a predecessor that never publishes (it cannot, short of a fault) ends the wait
