@@ -23,6 +23,22 @@ class Const(float):
     """A value made of literals only (folds to binary32)."""
 
 
+# Working precision of everything that is not a literal: binary64 by default; binary32 (every operation rounded
+# to float, as a GPU evaluates GLSL's highp float) to compare operation ORDER with a binary32 restatement bit for bit.
+REAL = np.float64
+
+
+def set_precision(real):
+    global REAL
+    if real not in (np.float32, np.float64):
+        raise GlslError("precision is np.float32 or np.float64")
+    REAL = real
+
+
+def R(x):
+    return REAL(x)
+
+
 TOKEN = re.compile(r"\s*(?:(\d+\.\d*(?:[eE][-+]?\d+)?[fF]?|\.\d+(?:[eE][-+]?\d+)?[fF]?|\d+[eE][-+]?\d+[fF]?)|(\d+)|([A-Za-z_]\w*)|(\+\+|--|<=|>=|==|!=|&&|\|\||[-+*/]=|[-+*/<>=!?:;,.(){}\[\]]))")
 TYPES = {"float", "int", "uint", "bool", "vec2", "vec3", "vec4", "ivec2", "ivec3", "uvec2", "uvec3", "mat3", "mat4", "void"}
 SWIZZLE = {c: i for i, c in enumerate("xyzw")} | {c: i for i, c in enumerate("rgba")}
@@ -245,8 +261,8 @@ class _Return(Exception):
 def _vec(*parts):
     flat = []
     for p in parts:
-        flat.extend(np.asarray(p, np.float64).reshape(-1).tolist())
-    return np.array(flat, np.float64)
+        flat.extend(np.asarray(p, REAL).reshape(-1).tolist())
+    return np.array(flat, REAL)
 
 
 def _ctor(n):
@@ -260,27 +276,64 @@ def _ctor(n):
     return make
 
 
+def _dot(a, b):
+    a, b = np.asarray(a, REAL), np.asarray(b, REAL)
+    acc = a[0] * b[0]
+    for i in range(1, a.size):
+        acc = acc + a[i] * b[i]  # left to right, every step rounded to the working precision
+    return R(acc)
+
+
 def _length(v):
-    return float(np.sqrt(np.dot(v, v)))
+    return R(np.sqrt(_dot(v, v)))
+
+
+_libm = None
+
+
+def _pow(x, y):
+    """pow in the working precision; in binary32 the C library's powf, so that a comparison with a C restatement
+    is not blurred by two implementations of the same function."""
+    global _libm
+    if REAL is np.float32:
+        if _libm is None:
+            import ctypes
+            _libm = ctypes.CDLL("libm.so.6")
+            _libm.powf.restype, _libm.powf.argtypes = ctypes.c_float, [ctypes.c_float, ctypes.c_float]
+        one = lambda a: np.float32(_libm.powf(float(a), float(y)))
+        return one(x) if np.ndim(x) == 0 else np.array([one(a) for a in np.asarray(x).reshape(-1)], np.float32).reshape(np.shape(x))
+    return np.power(R(x), R(y)) if np.ndim(x) == 0 else np.power(np.asarray(x, REAL), R(y))
+
+
+def _matmul(m, v):
+    """matrix * vector as the sum of the columns scaled by the vector's components, left to right (and the
+    same per column for matrix * matrix)."""
+    m, v = np.asarray(m, REAL), np.asarray(v, REAL)
+    if v.ndim == 2:
+        return np.stack([_matmul(m, v[:, c]) for c in range(v.shape[1])], axis=1)
+    acc = m[:, 0] * v[0]
+    for c in range(1, m.shape[1]):
+        acc = acc + m[:, c] * v[c]
+    return acc
 
 
 def _mat3(*cols):
     if len(cols) != 3 or any(np.size(c) != 3 for c in cols):
         raise GlslError("mat3 is built from three vec3 columns in the subset")
-    return np.stack([np.asarray(c, np.float64) for c in cols], axis=1)  # [row][column]
+    return np.stack([np.asarray(c, REAL) for c in cols], axis=1)  # [row][column]
 
 
 BUILTINS = {
     "mat3": _mat3, "nonuniformEXT": lambda x: x,
     "vec2": _ctor(2), "vec3": _ctor(3), "vec4": _ctor(4), "ivec2": lambda *a: _ctor(2)(*a).astype(np.int64),
-    "float": lambda x: float(x), "int": lambda x: int(x),
-    "dot": lambda a, b: float(np.dot(a, b)), "length": _length, "normalize": lambda v: np.asarray(v) / _length(v),
+    "float": lambda x: R(x), "int": lambda x: int(x),
+    "dot": _dot, "length": _length, "normalize": lambda v: np.asarray(v, REAL) * (R(1.0) / _length(v)),  # x * inversesqrt(dot(x, x)), as compilers expand it
     "sqrt": lambda x: np.sqrt(x), "inversesqrt": lambda x: 1.0 / np.sqrt(x),
-    "pow": lambda x, y: np.power(np.float64(x), np.float64(y)) if np.ndim(x) == 0 else np.power(np.asarray(x, np.float64), np.float64(y)),
+    "pow": lambda x, y: _pow(x, y),
     "max": lambda a, b: np.maximum(a, b) if np.ndim(a) or np.ndim(b) else (a if a > b else b) if not (a != a or b != b) else (b if a != a else a),
     "min": lambda a, b: np.minimum(a, b) if np.ndim(a) or np.ndim(b) else (a if a < b else b) if not (a != a or b != b) else (b if a != a else a),
     "clamp": lambda x, lo, hi: np.minimum(np.maximum(x, lo), hi),
-    "mix": lambda a, b, t: np.asarray(a, np.float64) * (1.0 - t) + np.asarray(b, np.float64) * t if np.ndim(a) or np.ndim(b) else a * (1.0 - t) + b * t,
+    "mix": lambda a, b, t: np.asarray(a, REAL) * (R(1.0) - R(t)) + np.asarray(b, REAL) * R(t) if np.ndim(a) or np.ndim(b) else R(a) * (R(1.0) - R(t)) + R(b) * R(t),
     "abs": lambda x: np.abs(x), "cross": lambda a, b: np.cross(a, b),
 }
 
@@ -302,14 +355,14 @@ class Interpreter:
             ret, params, body = self.funcs[name]
             if len(params) != len(args):
                 raise GlslError(f"{name}: {len(args)} arguments for {len(params)} parameters")
-            scope = {pn: (float(a) if pt == "float" and np.ndim(a) == 0 else a) for (pt, pn), a in zip(params, args)}
+            scope = {pn: (R(a) if pt == "float" and np.ndim(a) == 0 else a) for (pt, pn), a in zip(params, args)}
             try:
                 self.run(body, [scope])
             except _Return as r:
                 return r.value
             return None
         if name in self.builtins:
-            return self.builtins[name](*[float(a) if isinstance(a, Const) else a for a in args])
+            return self.builtins[name](*[R(a) if isinstance(a, (Const, float)) and not isinstance(a, bool) else a for a in args])
         raise GlslError(f"no function {name}")
 
     def lookup(self, name, scopes):
@@ -329,7 +382,7 @@ class Interpreter:
         elif kind == "decl":
             v = self.eval(node[3], scopes) if node[3] is not None else None
             if node[1] == "float" and v is not None:
-                v = float(v)
+                v = R(v)
             elif node[1] == "int" and v is not None:
                 v = int(v)
             scopes[-1][node[2]] = v
@@ -340,10 +393,10 @@ class Interpreter:
                     cur = s[node[1]]
                     if node[2] != "=":
                         rhs = self.arith(node[2][0], cur, rhs)
-                    s[node[1]] = float(rhs) if isinstance(rhs, Const) else rhs
+                    s[node[1]] = R(rhs) if isinstance(rhs, Const) else rhs
                     return
             if node[1] in self.globals and node[2] == "=":  # an `out` variable or a built-in output
-                self.globals[node[1]] = float(rhs) if isinstance(rhs, Const) else rhs
+                self.globals[node[1]] = R(rhs) if isinstance(rhs, Const) else rhs
                 return
             raise GlslError(f"assignment to unknown variable {node[1]}")
         elif kind == "if":
@@ -373,10 +426,14 @@ class Interpreter:
             return {"+": a + b, "-": a - b, "*": a * b}[op]
         x, y = (a, b)
         if op == "*" and np.ndim(x) == 2 and np.ndim(y) in (1, 2):
-            r = x @ y  # matrix * vector, matrix * matrix
+            r = _matmul(x, y)
+        elif np.ndim(x) == 0 and np.ndim(y) == 0:
+            x, y = R(x), R(y)
+            r = {"+": lambda: x + y, "-": lambda: x - y, "*": lambda: x * y, "/": lambda: x / y}[op]()
         else:
-            r = {"+": lambda: x + y, "-": lambda: x - y, "*": lambda: x * y, "/": lambda: x / y}[op]() if not (np.ndim(x) == 0 and np.ndim(y) == 0) else \
-                {"+": lambda: float(x) + float(y), "-": lambda: float(x) - float(y), "*": lambda: float(x) * float(y), "/": lambda: float(x) / float(y)}[op]()
+            x = np.asarray(x, REAL) if np.ndim(x) else R(x)
+            y = np.asarray(y, REAL) if np.ndim(y) else R(y)
+            r = {"+": lambda: x + y, "-": lambda: x - y, "*": lambda: x * y, "/": lambda: x / y}[op]()
         if both_const:
             return Const(np.float32(r))  # constant folding in the language's own precision
         return r
@@ -419,7 +476,7 @@ class Interpreter:
             if all(c in SWIZZLE for c in name):
                 arr = np.asarray(base)
                 picked = [arr[SWIZZLE[c]] for c in name]
-                return float(picked[0]) if len(picked) == 1 else np.array(picked, arr.dtype if arr.dtype.kind == "i" else np.float64)
+                return R(picked[0]) if len(picked) == 1 else np.array(picked, arr.dtype if arr.dtype.kind == "i" else REAL)
             raise GlslError(f"member {name}")
         if kind == "postinc":
             for s in reversed(scopes):
@@ -436,12 +493,12 @@ def run_deferred_shader(source: str, gbuf: dict, lights: np.ndarray, push: np.nd
     normal (H,W,4) float16, depth (H,W) float32 - sampled as the reference's nearest-filtered attachments are, at
     texel centres.  lights: (L,12) float32 std140 records; push: 20 floats (cameraPos, pointLightRadius, inverseVP
     column-major).  Returns what the shader passes to imageStore, (H,W,4) float64."""
-    planes = [gbuf["albedo"].astype(np.float64) / 255.0, gbuf["material"].astype(np.float64) / 255.0,
-              gbuf["normal"].astype(np.float64), np.repeat(gbuf["depth"].astype(np.float64)[..., None], 4, axis=-1)]
-    lights = np.asarray(lights, np.float32).reshape(-1, 12).astype(np.float64)
+    planes = [gbuf["albedo"].astype(REAL) / REAL(255.0), gbuf["material"].astype(REAL) / REAL(255.0),
+              gbuf["normal"].astype(REAL), np.repeat(gbuf["depth"].astype(REAL)[..., None], 4, axis=-1)]
+    lights = np.asarray(lights, np.float32).reshape(-1, 12).astype(REAL)
     records = [{"pos": r[0:3], "opening_angle": r[3], "color": r[4:7], "penumbra_angle": r[7], "dir": r[8:11], "_pad": r[11]} for r in lights]
-    push = np.asarray(push, np.float32).astype(np.float64)
-    out = np.zeros((height, width, 4), np.float64)
+    push = np.asarray(push, np.float32).astype(REAL)
+    out = np.zeros((height, width, 4), REAL)
 
     def texture(sampler, uv):
         x = min(max(int(np.floor(uv[0] * width)), 0), width - 1)
@@ -454,11 +511,11 @@ def run_deferred_shader(source: str, gbuf: dict, lights: np.ndarray, push: np.nd
     g = {"samplers": [0, 1, 2, 3], "outTex": "outTex",
          "push": {"cameraPos": push[0:3], "pointLightRadius": push[3], "inverseVP": push[4:20].reshape(4, 4).T},  # [row][col] from column-major
          "ubo": {"lights": records},
-         "gl_NumWorkGroups": np.array([width, height, 1], np.float64), "gl_WorkGroupSize": np.array([1, 1, 1], np.float64)}
+         "gl_NumWorkGroups": np.array([width, height, 1], REAL), "gl_WorkGroupSize": np.array([1, 1, 1], REAL)}
     interp = Interpreter(source, g, {"texture": texture, "imageStore": image_store})
     for y in range(height):
         for x in range(width):
-            g["gl_GlobalInvocationID"] = np.array([x, y, 0], np.float64)
+            g["gl_GlobalInvocationID"] = np.array([x, y, 0], REAL)
             interp.call("main", [])
     return out
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Runs the reference's deferred shader - its own text, /root/reference/shaders/deferred.comp, read at run time and
-evaluated by tests/glsl_eval.py in binary64 - on a small seeded frame and stores inputs and result:
+evaluated by tests/glsl_eval.py in binary64 and, operation by operation, in binary32 - on a small seeded frame and
+stores inputs and results:
 
     python tests/golden/make_shader_eval.py      ->  tests/golden/shader_text_eval_24x10_L13.npz
 
@@ -44,9 +45,17 @@ def make_case():
 def main():
     from glsl_eval import run_deferred_shader
     case = make_case()
-    out = run_deferred_shader(open(SHADER).read(), case["gbuf"], case["lights"], case["push"], W, H)
+    import glsl_eval
+    text = open(SHADER).read()
+    out = run_deferred_shader(text, case["gbuf"], case["lights"], case["push"], W, H)
+    glsl_eval.set_precision(np.float32)  # the same text with every operation rounded to binary32
+    try:
+        with np.errstate(all="ignore"):
+            out32 = run_deferred_shader(text, case["gbuf"], case["lights"], case["push"], W, H).astype(np.float32)
+    finally:
+        glsl_eval.set_precision(np.float64)
     np.savez_compressed(OUT, albedo=case["gbuf"]["albedo"], material=case["gbuf"]["material"], normal=case["gbuf"]["normal"],
-                        depth=case["gbuf"]["depth"], lights=case["lights"], push=case["push"], color=out)
+                        depth=case["gbuf"]["depth"], lights=case["lights"], push=case["push"], color=out, color_f32=out32)
     print(OUT, out.shape, float(out[..., :3].mean()))
 
 
