@@ -11,8 +11,10 @@
  * own text, evaluated per pixel in binary64 by tests/glsl_eval.py (a small
  * GLSL-subset evaluator; tests/test_shader_text_cpu.py and the fixture
  * tests/golden/shader_text_eval_*.npz made from such a run) - oracle_deferred_f64
- * agrees with it to 1e-12 - besides the known-answer cases in tests/.  How a
- * driver rounds pow / normalize / division remains outside any pin.
+ * agrees with it to 1e-12, and oracle_deferred_f32 is bit for bit the text
+ * evaluated with every operation rounded to binary32 - besides the known-answer
+ * cases in tests/.  How a driver rounds pow / normalize / division remains
+ * outside any pin.
  *
  * Three evaluations of the same algorithm are built from one body
  * (deferred_oracle_body.inc):
