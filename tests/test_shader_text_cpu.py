@@ -161,3 +161,45 @@ def test_shader_text_on_the_13_light_golden_frame(oracle):
     stored = z["out_mix_f64"][..., :3]
     close = np.abs(stored - text) <= 1e-4 * np.abs(text) + 2e-6
     assert close[ok & (z["near_threshold"] == 0)].mean() > 0.995
+
+
+@pytest.mark.skipif(not os.path.exists(VERT), reason="reference sources not present")
+def test_cull_planes_bound_the_clip_volume_of_the_vertex_shaders_position(oracle):
+    """The cull's rule is this build's own (the reference's prep_indirect.comp is empty), but the volume it tests
+    against is not: a point is inside the six planes of vkr_frustum_planes(vp) exactly when the gl_Position that
+    the reference's vertex shader - its text, /root/reference/shaders/offscreen.vert:31 - computes for it lies in
+    Vulkan's clip volume (-w <= x, y <= w, 0 <= z <= w).  Checked for model-space points under random model
+    matrices, leaving out points within rounding of a plane."""
+    from glsl_eval import Interpreter
+    synth = importlib.import_module("vk-renderer_amd.synth")
+    cam = synth.reference_camera(3840, 2160)
+    vp = np.asarray(cam["vp"], np.float64).reshape(4, 4).T  # [row][column]
+    planes = np.asarray(cam["planes"], np.float64)
+    rng = np.random.default_rng(8)
+    mats, points = [], []
+    for _ in range(6):
+        m = np.eye(4)
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        m[:3, :3] = q * rng.uniform(0.5, 3.0)
+        m[:3, 3] = rng.uniform(-40, 40, 3)
+        mats.append(m)
+    g = {"push": {"vp": vp}, "gl_DrawID": 0, "gl_InstanceIndex": 0, "gl_Position": None,
+         "ubo0": {"modelData": [{"matIdx": 0, "modelMatrixBaseIndex": 0}]}, "ubo1": {"modelMatrices": mats},
+         "inNormal": np.array([0.0, 0.0, 1.0]), "inTangent": np.array([1.0, 0.0, 0.0]), "inUV": np.zeros(3),
+         "outUV": None, "outTexOffset": None, "outTBN": None}
+    vert = Interpreter(open(VERT).read(), g, {})
+    inside_text, inside_planes, margin = [], [], []
+    for k in range(600):
+        g["ubo0"]["modelData"][0]["modelMatrixBaseIndex"] = k % len(mats)
+        world = np.asarray(cam["pos"], np.float64) + rng.normal(size=3) * np.array([300.0, 200.0, 400.0]) + np.array([0.0, 0.0, -150.0])
+        g["inPos"] = np.linalg.solve(mats[k % len(mats)], np.append(world, 1.0))[:3]  # model-space point that lands on `world`
+        vert.call("main", [])
+        x, y, z, w = g["gl_Position"]
+        inside_text.append(-w <= x <= w and -w <= y <= w and 0.0 <= z <= w)
+        d = planes[:, :3] @ world + planes[:, 3]
+        inside_planes.append(bool((d >= 0).all()))
+        margin.append(float(np.abs(d).min() / (np.abs(planes[:, :3]).sum(1).max() * np.abs(world).max() + 1.0)))
+    inside_text, inside_planes, margin = np.array(inside_text), np.array(inside_planes), np.array(margin)
+    clear = margin > 1e-5
+    assert clear.mean() > 0.95 and 0.1 < inside_text[clear].mean() < 0.9
+    assert np.array_equal(inside_text[clear], inside_planes[clear])
