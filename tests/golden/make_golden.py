@@ -98,7 +98,13 @@ def main():
     manifest["lights_camera.npz"] = {k: sha(v) for k, v in arrays.items()}
     manifest["lights_9.fscene"] = {"text": hashlib.sha256(text.encode()).hexdigest()}
 
-    with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
+    # fixtures made by other scripts (make_shader_eval.py) keep their entries
+    path = os.path.join(HERE, "MANIFEST.json")
+    if os.path.exists(path):
+        for name, entry in json.load(open(path)).items():
+            if name not in manifest and os.path.exists(os.path.join(HERE, name)):
+                manifest[name] = entry
+    with open(path, "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     for k in manifest:
         print(k, os.path.getsize(os.path.join(HERE, k)))

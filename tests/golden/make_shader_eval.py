@@ -56,6 +56,13 @@ def main():
         glsl_eval.set_precision(np.float64)
     np.savez_compressed(OUT, albedo=case["gbuf"]["albedo"], material=case["gbuf"]["material"], normal=case["gbuf"]["normal"],
                         depth=case["gbuf"]["depth"], lights=case["lights"], push=case["push"], color=out, color_f32=out32)
+    import hashlib
+    import json
+    manifest_path = os.path.join(HERE, "MANIFEST.json")
+    manifest = json.load(open(manifest_path))
+    z = np.load(OUT)
+    manifest[os.path.basename(OUT)] = {k: hashlib.sha256(np.ascontiguousarray(z[k]).tobytes()).hexdigest() for k in sorted(z.files)}
+    json.dump(manifest, open(manifest_path, "w"), indent=1, sort_keys=True)
     print(OUT, out.shape, float(out[..., :3].mean()))
 
 
