@@ -10,6 +10,8 @@ the "cull" object.  For N > 1 every rank shades its own frame (frame-batch paral
 collective in the timed region: weak scaling); the screen-band variant of ONE frame, its bands
 gathered on rank 0 over RCCL behind the next frame's resolve, is timed as well and reported under
 "band_sharded" with the gathered frame verified against rank 0's own whole-frame resolve.
+`python3 bench.py --gpus N` starts its own N ranks (one process per GPU, rendezvous on 127.0.0.1);
+under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it is one of the ranks.
 
 Prints ONE JSON line on rank 0.
 """
@@ -216,12 +218,18 @@ def main():
     ap.add_argument("--no-callers", action="store_true", help="skip the steps either side of the passes (bounds, G-buffer producers, camera path)")
     args = ap.parse_args()
 
+    # `python3 bench.py --gpus N` with no rank environment: this process becomes the parent of N fresh ranks (it has
+    # not touched the GPU: nothing imported so far does), relays rank 0's line and exits with the ranks' status.
+    launch = importlib.import_module("vk-renderer_amd.launch")
+    if launch.needs_spawn(args.gpus):
+        limit = float(os.environ.get("VKR_BENCH_TIME_LIMIT_S", "1500"))
+        raise SystemExit(launch.spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus, time_limit_s=limit,
+                                            is_result=lambda line: line.startswith('{"metric"')))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
 
     import torch
@@ -344,80 +352,33 @@ def main():
         del sets[1:], cargs
 
     # ---------------------------------------------------------------- deferred: one frame in bands
-    # torch sees the library's stream as an external stream: a collective issued while it is current is ordered
-    # after the kernels already on it, and waiting for the collective's work handle makes the library's stream (not
-    # the host) wait for the collective.
-    lib_stream = torch.cuda.ExternalStream(ctx.stream(), device=torch.device("cuda", device_index))
+    # The pipelines are the package's (vk-renderer_amd/dist.py): double-buffered band / command buffers, the gather
+    # of step k behind the compute of step k+1, a buffer rewritten only after the gather that read it was waited for.
+    if backend == "nccl" and world > 1:
+        transport = vdist.RcclTransport(ctx.stream(), device_index)
+    else:  # one rank, or the gloo rehearsal: the kernels fill device tensors, the gather goes through host memory
+        transport = vdist.HostTransport(device="cuda", sync=ctx.wait_idle)
 
-    def gather_to_rank0(send, recv_list):
-        """Asynchronous gather of equal-sized uint8 tensors to rank 0 (RCCL: grouped send/recv, one link per peer)."""
-        if backend == "nccl":
-            with torch.cuda.stream(lib_stream):
-                return dist.gather(send, recv_list if rank == 0 else None, dst=0, async_op=True)
-        ctx.wait_idle()  # rehearsal through host memory: the copy below is not ordered with the library's stream
-        host = send.cpu()
-        return dist.gather(host, recv_list if rank == 0 else None, dst=0, async_op=True)
-
-    def wait_work(work):
-        if work is None:
-            return
-        if backend == "nccl":
-            with torch.cuda.stream(lib_stream):
-                work.wait()  # stream-level: later kernels on the library's stream start after the gather
-        else:
-            work.wait()
+    def device_sync():
+        ctx.wait_idle()
+        torch.cuda.synchronize()
 
     def band_bench(gbuf, out_img, lights_buf, n_lights, push, flags, width, height):
-        """This rank resolves its band of rows of ONE frame and the bands are gathered on rank 0, K times.  The band
-        tensors are double-buffered: the gather of frame k runs on RCCL's stream while frame k+1 is resolved, and a
-        buffer is written again only after its previous gather has finished.  Afterwards rank 0 checks the gathered
-        frame against its own resolve of the whole frame (outside the timed region)."""
-        r0, r1 = vdist.band_rows(height, world, rank)
-        rows_max = vdist.band_rows(height, world, 0)[1]
-        pitch = out_img.pitch
-        bands = [torch.zeros(rows_max * pitch, dtype=torch.uint8, device="cuda") for _ in range(2)]
-        recv = [[torch.zeros(rows_max * pitch, dtype=torch.uint8, device=coll_device) for _ in range(world)] if rank == 0 else None for _ in range(2)]
-        bargs = []
-        for t in bands:
-            a = vkr.make_deferred_args(gbuf, out_img, lights_buf, n_lights, push, flags=flags, row0=r0, rows=r1 - r0)
-            a.out = vkr.Image2D(t.data_ptr(), width, r1 - r0, pitch, vkr.FORMAT_R8G8B8A8_UNORM)
-            bargs.append(a)
-        works = [None, None]
-
-        def band_step(k):
-            b = k & 1
-            wait_work(works[b])  # the gather that last read this buffer
-            ctx.deferred_resolve(bargs[b])
-            works[b] = gather_to_rank0(bands[b], recv[b])
-
-        for k in range(WU):
-            band_step(k)
-        for w_ in works:
-            wait_work(w_)
-        ctx.wait_idle()
-        torch.cuda.synchronize()
-        barrier()
-        tb0 = time.perf_counter()
-        for k in range(K):
-            band_step(k)
-        for w_ in works:
-            wait_work(w_)
-        ctx.wait_idle()
-        torch.cuda.synchronize()
-        barrier()
-        tb = max_over_ranks(time.perf_counter() - tb0)
+        """This rank resolves its band of rows of ONE frame and the bands are gathered on rank 0, K times
+        (dist.BandShardedResolve).  Afterwards rank 0 checks the gathered frame against its own resolve of the
+        whole frame (outside the timed region)."""
+        pipe = vdist.BandShardedResolve(transport, width, height, out_img.pitch,
+                                        vdist.hip_band_resolver(vkr, ctx, gbuf, out_img, lights_buf, n_lights, push, flags))
+        tb = vdist.timed_steps(transport, pipe, K, WU, device_sync)
+        got = pipe.frame()
         verified = None
         if rank == 0:
             ctx.deferred_resolve(vkr.make_deferred_args(gbuf, out_img, lights_buf, n_lights, push, flags=flags))
             ctx.wait_idle()
-            whole = out_img.download(np.uint8, 4)
-            last = recv[(K - 1) & 1]
-            got = np.concatenate([last[r].cpu().numpy().reshape(rows_max, pitch)[: vdist.band_rows(height, world, r)[1] - vdist.band_rows(height, world, r)[0], : width * 4]
-                                  for r in range(world)]).reshape(height, width, 4)
-            verified = bool(np.array_equal(got, whole))
+            verified = bool(np.array_equal(got, out_img.download(np.uint8, 4)))
         return {"value": float(width) * height * K / tb / 1e9, "unit": "Gpixel/s", "ms_per_frame": tb / K * 1e3, "scaling": "strong",
                 "collective": "gather of rgba8 bands to rank 0 (RCCL), double-buffered: the gather of frame k overlaps the resolve of frame k+1",
-                "verified": verified}
+                "band_rows": [list(vdist.band_rows(height, world, r)) for r in range(world)], "verified": verified}
 
     if world > 1:
         frame = synth.deferred_case(W, H, L, config_index=1)  # the same frame on every rank
@@ -469,51 +430,18 @@ def main():
             # ONE scene split into instance ranges on mesh boundaries, one range per rank; the only exchange is the
             # gather of the per-mesh commands (20 bytes per mesh), the compacted lists stay where they were made
             shared = synth.cull_case(N, M, config_index=2)
-            cuts = vdist.mesh_range_cuts(shared["mesh_base"], N, world)
-            m0, m1, i0, i1 = cuts[rank]
-            part = vkr.CullScene(ctx, shared["aabb_min"][i0:i1], shared["aabb_max"][i0:i1], shared["mesh_base"][m0:m1] - np.uint32(i0),
-                                 shared["cmd_template"][m0:m1], first_mesh=m0, first_instance=i0)
-            cap = max(max(c[1] - c[0] for c in cuts) * 20, 16)
-            mine = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in range(2)]
-            recv = [[torch.zeros(cap, dtype=torch.uint8, device=coll_device) for _ in range(world)] if rank == 0 else None for _ in range(2)]
-            pargs = []
-            for t in mine:
-                a = part.args(shared["planes"], 0)
-                a.cmd_out = t.data_ptr()  # the commands of this rank's meshes land in the tensor that is gathered
-                pargs.append(a)
-            works = [None, None]
-
-            def range_step(k):
-                b = k & 1
-                wait_work(works[b])
-                ctx.prep_indirect(pargs[b])
-                works[b] = gather_to_rank0(mine[b], recv[b])
-
-            for k in range(WU):
-                range_step(k)
-            for w_ in works:
-                wait_work(w_)
-            ctx.wait_idle()
-            torch.cuda.synchronize()
-            barrier()
-            r0_ = time.perf_counter()
-            for k in range(K):
-                range_step(k)
-            for w_ in works:
-                wait_work(w_)
-            ctx.wait_idle()
-            torch.cuda.synchronize()
-            barrier()
-            rt = max_over_ranks(time.perf_counter() - r0_)
+            rpipe = vdist.RangeShardedCull(transport, shared["mesh_base"], N, vdist.hip_range_culler(vkr, ctx, shared, shared["planes"], 0))
+            cuts = rpipe.cuts
+            rt = vdist.timed_steps(transport, rpipe, K, WU, device_sync)
+            got = rpipe.commands()
             verified = None
             if rank == 0:  # the assembled command buffer against this rank's cull of the whole scene
                 whole = vkr.CullScene(ctx, shared["aabb_min"], shared["aabb_max"], shared["mesh_base"], shared["cmd_template"])
                 whole.run(shared["planes"], 0)
                 ctx.wait_idle()
-                last = recv[(K - 1) & 1]
-                got = b"".join(last[r].cpu().numpy()[: (cuts[r][1] - cuts[r][0]) * 20].tobytes() for r in range(world))
                 verified = got == whole.results()["cmds"].tobytes()
                 del whole
+            del rpipe
             cull["range_sharded"] = {"value": float(N) * K / rt / 1e9, "unit": "G instances/s", "ms_per_call": rt / K * 1e3, "scaling": "strong",
                                      "collective": "gather of the per-mesh commands to rank 0 (RCCL), double-buffered",
                                      "ranges": [[int(c[2]), int(c[3])] for c in cuts], "verified": verified}

@@ -46,5 +46,53 @@ def test_bench_refuses_to_run_without_a_gpu():
         pytest.skip("a GPU is present")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "MI355X" in (r.stderr + r.stdout)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300)
-    assert r.returncode != 0 and "torch.distributed.run" in (r.stderr + r.stdout)
+    # --gpus 2 without a rank environment: bench.py starts its own two ranks, both fail loudly, and so does the parent
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "MI355X" in (r.stderr + r.stdout) and "exited with status" in r.stderr
+    # under a launcher that set another world size
+    env = dict(os.environ, RANK="0", WORLD_SIZE="4")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "does not match WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+RANK_SCRIPT = r"""
+import json, os, sys, time
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0 and os.environ["LOCAL_RANK"] == str(rank)
+mode = sys.argv[1]
+if mode == "ok":
+    print("noise from rank", rank) if rank else print("library chatter\n" + json.dumps({"world": world, "pad": "x" * 200000}))
+elif mode == "fail" and rank == 1:
+    sys.exit(7)
+elif mode == "fail":
+    time.sleep(600)  # a rank waiting for a dead peer: the parent must end it
+elif mode == "hang":
+    time.sleep(600)
+"""
+
+
+def test_rank_launcher(tmp_path):
+    """The parent of `bench.py --gpus N`: N ranks with the rendezvous environment, rank 0's output relayed (also
+    when it is longer than a pipe holds), a failing rank or the time limit ends the run with a non-zero status."""
+    import importlib
+    import io
+    import json
+    import time
+    launch = importlib.import_module("vk-renderer_amd.launch")
+    assert launch.needs_spawn(2, {}) and not launch.needs_spawn(1, {})
+    assert not launch.needs_spawn(2, {"RANK": "0", "WORLD_SIZE": "2"}) and not launch.needs_spawn(2, {"WORLD_SIZE": "2"})
+    script = tmp_path / "rank.py"
+    script.write_text(RANK_SCRIPT)
+    out, err = io.StringIO(), open(tmp_path / "err.txt", "w+")
+    assert launch.spawn_ranks([str(script), "ok"], 3, time_limit_s=120, out=out, err=err, is_result=lambda l: l.startswith("{")) == 0
+    line = json.loads(out.getvalue())  # one line: what is not a result went to err
+    assert line["world"] == 3 and len(line["pad"]) == 200000 and "noise" not in out.getvalue()
+    t0 = time.monotonic()
+    assert launch.spawn_ranks([str(script), "fail"], 2, time_limit_s=120, out=io.StringIO(), err=err) == 7
+    assert time.monotonic() - t0 < 60
+    t0 = time.monotonic()
+    assert launch.spawn_ranks([str(script), "hang"], 2, time_limit_s=2, out=io.StringIO(), err=err) == 124
+    assert time.monotonic() - t0 < 60
+    err.seek(0)
+    text = err.read()
+    assert "rank 1 exited with status 7" in text and "time limit" in text and "library chatter" in text

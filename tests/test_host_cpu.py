@@ -176,6 +176,73 @@ cmds, visible = vdist.sharded_cull(scene["mesh_base"], 3000, 2, rank, rng, vdist
 ref = oracle.cull(scene["aabb_min"], scene["aabb_max"], scene["planes"], scene["mesh_base"], scene["cmd_template"])
 assert cmds.tobytes() == ref["cmds"].tobytes(), "sharded command buffer differs"
 assert np.array_equal(visible, ref["visible"]), "sharded visible list differs"
+# ---- the double-buffered gather-to-rank-0 pipelines (what bench.py --gpus N times), oracle injected as compute
+class Checked(vdist.HostTransport):
+    """Fails the run if a send buffer is handed to a fill while a gather that read it has not been waited for."""
+    def __init__(self):
+        super().__init__(device="cpu")
+        self.reading = {{}}  # data_ptr -> work not yet waited for
+        self.gathers = self.waits = 0
+    def gather_async(self, send, recv_list):
+        assert send.data_ptr() not in self.reading, "gather issued on a buffer whose previous gather is still pending"
+        w = super().gather_async(send, recv_list)
+        self.reading[send.data_ptr()] = w
+        self.gathers += 1
+        return w
+    def wait(self, work):
+        super().wait(work)
+        if work is not None:
+            self.waits += 1
+            for k in [k for k, v in self.reading.items() if v is work]:
+                del self.reading[k]
+tr = Checked()
+W, H = 40, 23  # 23 rows over 2 ranks: bands of 12 and 11 rows
+pitch = W * 4 + 16
+frames = [synth.deferred_case(W, H, 5, config_index=3 + k) for k in range(5)]
+state = {{"k": 0}}
+def resolve_band(buf, r0, r1):
+    assert buf.data_ptr() not in tr.reading, "buffer rewritten before its gather was waited for"
+    c = frames[state["k"]]
+    img = oracle.deferred(c["gbuf"], c["lights"], c["push"], mode="f32", rows=(r0, r1))["rgba8"][r0:r1]
+    view = buf.numpy().reshape(-1, pitch)
+    view[: r1 - r0, : W * 4] = img.reshape(r1 - r0, W * 4)
+bands = vdist.BandShardedResolve(tr, W, H, pitch, resolve_band)
+assert (bands.r0, bands.r1) == ((0, 12) if rank == 0 else (12, 23)) and bands.rows_max == 12
+for k in range(5):  # five frames through two buffers: every buffer is reused at least once
+    state["k"] = k
+    bands.step()
+    if k in (1, 4):
+        got = bands.frame()
+        if rank == 0:
+            c = frames[k]
+            want = oracle.deferred(c["gbuf"], c["lights"], c["push"], mode="f32")["rgba8"]
+            assert np.array_equal(got, want), f"pipelined band gather differs at frame {{k}}"
+        else:
+            assert got is None
+assert tr.gathers == 5 and tr.waits == 5 and not tr.reading
+# timed_steps drives the same pipeline (warm-up + steps, drained on both sides)
+state["k"] = 2
+seconds = vdist.timed_steps(tr, bands, 3, 1, lambda: None)
+assert seconds > 0 and not tr.reading
+got = bands.frame()
+if rank == 0:
+    assert np.array_equal(got, oracle.deferred(frames[2]["gbuf"], frames[2]["lights"], frames[2]["push"], mode="f32")["rgba8"])
+# instance ranges: commands of this rank's meshes into the gathered buffer
+def cull_range(buf, m0, m1, i0, i1):
+    assert buf.data_ptr() not in tr.reading
+    cm, _ = rng(m0, m1, i0, i1)
+    raw = np.ascontiguousarray(cm).view(np.uint8).reshape(-1)
+    buf.numpy()[: raw.size] = raw
+ranges = vdist.RangeShardedCull(tr, scene["mesh_base"], 3000, cull_range)
+assert ranges.cuts == vdist.mesh_range_cuts(scene["mesh_base"], 3000, 2)
+for _ in range(3):
+    ranges.step()
+cmd_bytes = ranges.commands()
+if rank == 0:
+    assert cmd_bytes == ref["cmds"].tobytes(), "pipelined command gather differs"
+else:
+    assert cmd_bytes is None
+assert not tr.reading
 dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
@@ -183,7 +250,9 @@ print("rank", rank, "ok")
 
 def test_two_process_gloo_sharding(tmp_path):
     """world_size 2 on CPU (gloo): the band gather and the mesh-range cull assembly reproduce the
-    single-process result.  The per-rank compute is the oracle standing in for the HIP entry points."""
+    single-process result, through the all-gather helpers and through the double-buffered gather-to-rank-0
+    pipelines that bench.py --gpus N times (uneven bands, buffers reused only after their gather was waited
+    for).  The per-rank compute is the oracle standing in for the HIP entry points."""
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -96,3 +96,252 @@ def torch_all_gather_numpy(x: np.ndarray) -> list[np.ndarray]:
         a = b[:int(s.item())].numpy().view(x.dtype)
         out.append(a.reshape((-1,) + tail))
     return out
+
+
+# ----------------------------------------------------------------------------------------------- pipelines
+# One frame (or one scene) split over the ranks, its pieces gathered on rank 0, step after step.  The piece
+# buffers are double-buffered and the gather is asynchronous: the gather of step k runs while step k+1 is
+# computed, and a buffer is written again only after the gather that last read it has been waited for.
+# How buffers are allocated, gathered and waited for is the transport's business (RCCL on device tensors
+# ordered through the library's stream, or gloo through host memory); what fills a buffer is injected by the
+# caller (the HIP entry points in production, a stand-in in CPU tests).
+
+class HostTransport:
+    """gloo through host memory.  `device`: where the send buffers live ("cpu", or "cuda" when a kernel fills
+    them and the gather is a rehearsal on a box with fewer GPUs than ranks); `sync`: called before a send
+    buffer is copied to the host (the library's wait_idle), None for CPU buffers."""
+
+    name = "gloo"
+
+    def __init__(self, device: str = "cpu", sync: Callable[[], None] | None = None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.device, self.sync = device, sync
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+
+    def alloc_send(self, nbytes: int):
+        return self.torch.zeros(nbytes, dtype=self.torch.uint8, device=self.device)
+
+    def alloc_recv(self, nbytes: int):
+        return self.torch.zeros(nbytes, dtype=self.torch.uint8)
+
+    def gather_async(self, send, recv_list):
+        if self.sync is not None:
+            self.sync()  # the copy below is not ordered with the library's stream
+        host = send.cpu() if send.device.type != "cpu" else send
+        if self.world == 1:
+            recv_list[0].copy_(host)
+            return None
+        return self.dist.gather(host, recv_list if self.rank == 0 else None, dst=0, async_op=True)
+
+    def wait(self, work):
+        if work is not None:
+            work.wait()
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max_over_ranks(self, value: float) -> float:
+        if self.world == 1:
+            return value
+        t = self.torch.tensor([value], dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def to_numpy(self, tensor) -> np.ndarray:
+        return tensor.cpu().numpy()
+
+
+class RcclTransport:
+    """RCCL on device tensors.  torch sees the library's stream as an external stream: a collective issued
+    while it is current is ordered after the kernels already on it, and waiting for the collective's work
+    handle makes that stream (not the host) wait for the collective.  Under RCCL a gather is a group of
+    point-to-point transfers: rank 0 receives from each peer over that peer's own xGMI link."""
+
+    name = "nccl"
+
+    def __init__(self, hip_stream: int, device_index: int):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.device = torch.device("cuda", device_index)
+        self.stream = torch.cuda.ExternalStream(hip_stream, device=self.device)
+
+    def alloc_send(self, nbytes: int):
+        return self.torch.zeros(nbytes, dtype=self.torch.uint8, device=self.device)
+
+    alloc_recv = alloc_send
+
+    def gather_async(self, send, recv_list):
+        with self.torch.cuda.stream(self.stream):
+            return self.dist.gather(send, recv_list if self.rank == 0 else None, dst=0, async_op=True)
+
+    def wait(self, work):
+        if work is not None:
+            with self.torch.cuda.stream(self.stream):
+                work.wait()  # stream-level: later kernels on the library's stream start after the gather
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def max_over_ranks(self, value: float) -> float:
+        t = self.torch.tensor([value], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def to_numpy(self, tensor) -> np.ndarray:
+        return tensor.cpu().numpy()
+
+
+class GatherPipeline:
+    """`slots` send buffers of `nbytes` per rank and, on rank 0, `slots` sets of `world` receive buffers.
+    step(fill): waits for the gather that last read the next buffer, calls fill(buffer) (which enqueues or
+    performs the work that writes it) and starts the buffer's gather.  drain(): waits for every gather."""
+
+    def __init__(self, transport, nbytes: int, slots: int = 2):
+        self.t = transport
+        self.slots = slots
+        self.send = [transport.alloc_send(nbytes) for _ in range(slots)]
+        self.recv = [[transport.alloc_recv(nbytes) for _ in range(transport.world)] if transport.rank == 0 else None for _ in range(slots)]
+        self.works = [None] * slots
+        self.steps = 0
+
+    def step(self, fill: Callable[[object], None]):
+        b = self.steps % self.slots
+        self.t.wait(self.works[b])  # the gather that last read this buffer
+        self.works[b] = None
+        fill(self.send[b])
+        self.works[b] = self.t.gather_async(self.send[b], self.recv[b])
+        self.steps += 1
+
+    def drain(self):
+        for b in range(self.slots):
+            self.t.wait(self.works[b])
+            self.works[b] = None
+
+    def latest(self):
+        """Rank 0: the receive buffers of the most recent step (call drain() first)."""
+        assert self.steps > 0
+        return self.recv[(self.steps - 1) % self.slots]
+
+
+class BandShardedResolve:
+    """ONE frame resolved in horizontal bands, one band per rank, the rgba8 bands gathered on rank 0.
+    resolve_band(buffer, r0, r1) shades rows [r0, r1) of the full frame into `buffer` (row pitch `pitch`
+    bytes, band-relative rows); in production it is vkr_deferred_resolve with row_offset / full_height and
+    the output image pointing at the buffer."""
+
+    def __init__(self, transport, width: int, height: int, pitch: int, resolve_band: Callable[[object, int, int], None], slots: int = 2):
+        self.t, self.width, self.height, self.pitch = transport, width, height, pitch
+        self.r0, self.r1 = band_rows(height, transport.world, transport.rank)
+        self.rows_max = band_rows(height, transport.world, 0)[1]
+        self.resolve_band = resolve_band
+        self.pipe = GatherPipeline(transport, max(self.rows_max * pitch, 16), slots)
+
+    def step(self):
+        self.pipe.step(lambda buf: self.resolve_band(buf, self.r0, self.r1))
+
+    def drain(self):
+        self.pipe.drain()
+
+    def frame(self) -> np.ndarray | None:
+        """Rank 0: the most recent frame, (height, width, 4) uint8, assembled from the gathered bands."""
+        self.pipe.drain()
+        if self.t.rank != 0:
+            return None
+        parts = []
+        for r, buf in enumerate(self.pipe.latest()):
+            a, b = band_rows(self.height, self.t.world, r)
+            parts.append(self.t.to_numpy(buf).reshape(self.rows_max, self.pitch)[: b - a, : self.width * 4])
+        return np.concatenate(parts).reshape(self.height, self.width, 4)
+
+
+class RangeShardedCull:
+    """ONE scene culled in instance ranges cut on mesh boundaries, one range per rank.  The only exchange is the
+    gather of the per-mesh commands (20 bytes per mesh) to rank 0; the compacted lists stay on the rank that
+    made them.  cull_range(buffer, m0, m1, i0, i1) culls meshes [m0, m1) = instances [i0, i1) and leaves their
+    commands at the start of `buffer` (production: vkr_prep_indirect with first_mesh / first_instance and
+    cmd_out pointing at the buffer)."""
+
+    CMD_BYTES = 20
+
+    def __init__(self, transport, mesh_base: np.ndarray, instance_count: int, cull_range: Callable[[object, int, int, int, int], None], slots: int = 2):
+        self.t = transport
+        self.cuts = mesh_range_cuts(mesh_base, instance_count, transport.world)
+        self.mine = self.cuts[transport.rank]
+        self.cull_range = cull_range
+        cap = max(max(c[1] - c[0] for c in self.cuts) * self.CMD_BYTES, 16)
+        self.pipe = GatherPipeline(transport, cap, slots)
+
+    def step(self):
+        self.pipe.step(lambda buf: self.cull_range(buf, *self.mine))
+
+    def drain(self):
+        self.pipe.drain()
+
+    def commands(self) -> bytes | None:
+        """Rank 0: the command buffer of the whole scene (mesh order), from the most recent step."""
+        self.pipe.drain()
+        if self.t.rank != 0:
+            return None
+        return b"".join(self.t.to_numpy(buf)[: (c[1] - c[0]) * self.CMD_BYTES].tobytes() for buf, c in zip(self.pipe.latest(), self.cuts))
+
+
+def timed_steps(transport, pipeline, steps: int, warmup: int, device_sync: Callable[[], None]) -> float:
+    """Seconds (max over ranks) for `steps` steps of a pipeline after `warmup` untimed ones, every gather
+    finished on both sides of the timed region."""
+    import time
+    for _ in range(warmup):
+        pipeline.step()
+    pipeline.drain()
+    device_sync()
+    transport.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipeline.step()
+    pipeline.drain()
+    device_sync()
+    transport.barrier()
+    return transport.max_over_ranks(time.perf_counter() - t0)
+
+
+def hip_band_resolver(vkr, ctx, gbuf, out_img, lights_buf, light_count: int, push, flags: int = 0):
+    """resolve_band of BandShardedResolve on the HIP path: vkr_deferred_resolve of rows [r0, r1) with the output
+    image placed in the transport's buffer (rgba8, the pitch of `out_img`)."""
+    cache = {}
+
+    def resolve_band(buf, r0, r1):
+        a = cache.get(buf.data_ptr())
+        if a is None:
+            a = vkr.make_deferred_args(gbuf, out_img, lights_buf, light_count, push, flags=flags, row0=r0, rows=r1 - r0)
+            a.out = vkr.Image2D(buf.data_ptr(), gbuf.width, r1 - r0, out_img.pitch, vkr.FORMAT_R8G8B8A8_UNORM)
+            cache[buf.data_ptr()] = a
+        ctx.deferred_resolve(a)
+
+    return resolve_band
+
+
+def hip_range_culler(vkr, ctx, scene: dict, planes, flags: int = 0):
+    """cull_range of RangeShardedCull on the HIP path: this rank's slice of `scene` (host arrays aabb_min, aabb_max,
+    mesh_base, cmd_template) is uploaded once; each call is vkr_prep_indirect with first_mesh / first_instance set and
+    cmd_out pointing at the transport's buffer."""
+    state = {}
+
+    def cull_range(buf, m0, m1, i0, i1):
+        part = state.get("part")
+        if part is None:
+            part = vkr.CullScene(ctx, scene["aabb_min"][i0:i1], scene["aabb_max"][i0:i1], scene["mesh_base"][m0:m1] - np.uint32(i0),
+                                 scene["cmd_template"][m0:m1], first_mesh=m0, first_instance=i0)
+            state["part"] = part
+        a = state.get(buf.data_ptr())
+        if a is None:
+            a = part.args(planes, flags)
+            a.cmd_out = buf.data_ptr()  # the commands of this rank's meshes land in the buffer that is gathered
+            state[buf.data_ptr()] = a
+        ctx.prep_indirect(a)
+
+    return cull_range
