@@ -79,6 +79,58 @@ def timed(ctx, fn, iters, warmup):
     return e1.elapsed_ms_since(e0) / iters
 
 
+TILED_WORKLOADS = {  # name -> (width, height, lights, radius): the radius-cutoff lines of the "callers" object
+    "tiled_resolve_4k_256": (3840, 2160, 256, 25.0),
+    "tiled_resolve_4k_4096": (3840, 2160, 4096, 25.0),
+    "tiled_resolve_8k": (7680, 4320, 4096, 25.0),
+    "tiled_resolve_8k_discontinuous": (7680, 4320, 4096, 25.0),  # depth uncorrelated between neighbouring pixels
+}
+
+
+def tiled_line(ctx, vkr, synth, frame, K, WU, name, pmc):
+    """One radius-cutoff resolve with light lists, timed.  L_eff = mean number of lights a pixel's loop walked, measured
+    from the lists of the timed frame; frac = max(algorithmic bytes / t / HBM peak, flops(L_eff) / t / VALU peak)."""
+    Wt, Ht, Lt, Rt = TILED_WORKLOADS[name]
+    caset = synth.deferred_case(64, 36, Lt, config_index=3)
+    if name.endswith("_discontinuous"):
+        # the parity tests' G-buffer at full size: a tile's depth range spans hundreds of world units
+        noisy = synth.deferred_case(Wt, Ht, Lt, config_index=3)
+        gbt = vkr.GBuffer(ctx, Wt, Ht).upload(noisy["gbuf"])
+        caset = noisy
+        scene = "G-buffer with depth uncorrelated between neighbouring pixels"
+    else:
+        gbt = vkr.GBuffer(ctx, Wt, Ht)
+        camt = synth.reference_camera(Wt, Ht)
+        sbuf = ctx.buffer_from(synth.make_spheres(64))
+        frame.gbuffer_fill(ctx, gbt, sbuf, frame.make_gbuffer_scene(camt["vp"], camt["inv_vp"], camt["pos"], 64))
+        ctx.wait_idle()
+        scene = "analytic G-buffer"
+    pusht = caset["push"].copy()
+    pusht[3] = Rt
+    lightst = ctx.buffer_from(caset["lights"])
+    outt = ctx.image(vkr.FORMAT_R8G8B8A8_UNORM, Wt, Ht)
+    targs = vkr.make_deferred_args(gbt, outt, lightst, Lt, pusht, flags=vkr.DEFERRED_RADIUS_CUTOFF)
+    ms = timed(ctx, lambda: ctx.deferred_resolve(targs), K, WU)
+    st = ctx.tile_stats()
+    l_eff = st["mean_lights_per_pixel"]
+    byt = Wt * Ht * 24.0
+    flops = Wt * Ht * (150.0 + 117.0 * l_eff)
+    hbm_frac, valu_frac = byt / (ms * 1e-3) / HBM_PEAK, flops / (ms * 1e-3) / VALU_FP32_PEAK
+    line = {"value": Wt * Ht / (ms * 1e-3) / 1e9, "unit": "Gpixel/s", "ms_per_call": ms, "lights": Lt, "radius": Rt,
+            "workload": f"{Wt}x{Ht}, {Lt} lights, radius cutoff {Rt}, coarse bins + per-tile light lists, {scene}",
+            "L_eff": l_eff, "lists": {k: st[k] for k in ("tiles", "dark_tiles", "listed_tiles", "overflow_tiles", "max_list", "list_cap")},
+            "roofline": {"bound": "hbm" if hbm_frac >= valu_frac else "valu_fp32", "frac": max(hbm_frac, valu_frac), "hbm_frac": hbm_frac,
+                         "valu_frac": valu_frac, "algorithmic_bytes": byt, "algorithmic_flops": flops, "traffic": None, "dram_frac": None},
+            "hbm_frac": hbm_frac, "algorithmic_bytes": byt}
+    # HBM bytes the launches of one call really moved (PMC passes of this workload alone): dark tiles cost 12 of the 24
+    # bytes per pixel, so the DRAM rate is below what the algorithmic bytes suggest - both fractions are in the line
+    traffic = pmc.get(name)
+    if traffic is not None:
+        line["roofline"]["traffic"] = traffic
+        line["roofline"]["dram_frac"] = traffic / (ms * 1e-3) / HBM_PEAK
+    return line, (gbt, outt, lightst, pusht)
+
+
 def bench_callers(ctx, vkr, synth, vdist, args, K, WU, rank, world, barrier, max_over_ranks, band_bench, pmc):
     """The steps before the two passes, each on the headline sizes: per-instance bounds (2^22 instances),
     G-buffer attachment encode and analytic fill (4K), and the 64-frame camera path (cull + fill + resolve
@@ -139,41 +191,26 @@ def bench_callers(ctx, vkr, synth, vdist, args, K, WU, rank, world, barrier, max
                                         "frac": byt / (ms * 1e-3) / HBM_PEAK, "traffic": pmc.get("gbuffer_fill_kernel"), "algorithmic_bytes": byt,
                                         "flops_if_every_sphere_were_tested": W * H * (110.0 + 9.0 * 64)}}
 
-    # Radius cutoff with light lists on the analytic scene (coherent depth): the 8K x 4096-light configuration and the
-    # two 4K ones.  L_eff = mean number of lights a pixel's loop walked, measured from the lists of the timed frame;
-    # frac = max(algorithmic bytes / t / HBM peak, flops(L_eff) / t / VALU peak).
-    tiled_kernels = PMC_TILED
+    # The whole-table resolve (the reference's rule: every light on every pixel) over that analytic G-buffer: the sky's
+    # waves have no pixel a light can change and do not walk the table, and over one surface the trips whose lights
+    # all lie behind it are cut short (both exact: same bytes).  Reported with the nominal work of the headline formula.
+    lights_a = ctx.buffer_from(synth.deferred_case(64, 36, L, config_index=5)["lights"])
+    out_a = ctx.image(vkr.FORMAT_R8G8B8A8_UNORM, W, H)
+    wargs = vkr.make_deferred_args(gb, out_a, lights_a, L, vkr.deferred_push(cam["pos"], cam["inv_vp"]))
+    ms = timed(ctx, lambda: ctx.deferred_resolve(wargs), K, WU)
+    _, wflops = deferred_algorithmic(W, H, L)
+    out["whole_table_analytic"] = {"value": W * H / (ms * 1e-3) / 1e9, "unit": "Gpixel/s", "ms_per_call": ms, "lights": L,
+                                   "workload": f"{W}x{H}, {L} lights, no cutoff, analytic G-buffer (sky + ground + 64 spheres)",
+                                   "nominal_valu_frac": wflops / (ms * 1e-3) / VALU_FP32_PEAK}
+    del lights_a, out_a
 
-    def tiled_line(Wt, Ht, Lt, Rt, profiled=False):
-        gbt = gb if (Wt, Ht) == (W, H) else vkr.GBuffer(ctx, Wt, Ht)
-        camt = synth.reference_camera(Wt, Ht)
-        frame.gbuffer_fill(ctx, gbt, sbuf, frame.make_gbuffer_scene(camt["vp"], camt["inv_vp"], camt["pos"], 64))
-        caset = synth.deferred_case(64, 36, Lt, config_index=3)
-        pusht = caset["push"].copy()
-        pusht[3] = Rt
-        lightst = ctx.buffer_from(caset["lights"])
-        outt = ctx.image(vkr.FORMAT_R8G8B8A8_UNORM, Wt, Ht)
-        targs = vkr.make_deferred_args(gbt, outt, lightst, Lt, pusht, flags=vkr.DEFERRED_RADIUS_CUTOFF)
-        ms = timed(ctx, lambda: ctx.deferred_resolve(targs), K, WU)
-        st = ctx.tile_stats()
-        l_eff = st["mean_lights_per_pixel"]
-        byt = Wt * Ht * 24.0
-        flops = Wt * Ht * (150.0 + 117.0 * l_eff)
-        hbm_frac, valu_frac = byt / (ms * 1e-3) / HBM_PEAK, flops / (ms * 1e-3) / VALU_FP32_PEAK
-        line = {"value": Wt * Ht / (ms * 1e-3) / 1e9, "unit": "Gpixel/s", "ms_per_call": ms, "lights": Lt, "radius": Rt,
-                "workload": f"{Wt}x{Ht}, {Lt} lights, radius cutoff {Rt}, coarse bins + per-tile light lists, analytic G-buffer",
-                "L_eff": l_eff, "lists": {k: st[k] for k in ("tiles", "dark_tiles", "listed_tiles", "overflow_tiles", "max_list", "list_cap")},
-                "roofline": {"bound": "hbm" if hbm_frac >= valu_frac else "valu_fp32", "frac": max(hbm_frac, valu_frac), "hbm_frac": hbm_frac,
-                             "valu_frac": valu_frac, "algorithmic_bytes": byt, "algorithmic_flops": flops,
-                             "traffic": sum(pmc[k] for k in tiled_kernels) if profiled and all(k in pmc for k in tiled_kernels) else None},
-                "hbm_frac": hbm_frac, "algorithmic_bytes": byt}
-        return line, (gbt, outt, lightst, pusht)
-
-    if not args.tiled_8k_only:
-        out["tiled_resolve_4k_256"], _ = tiled_line(W, H, 256, 25.0)
-        out["tiled_resolve_4k_4096"], _ = tiled_line(W, H, 4096, 25.0)
-    W8, H8, L8, R8 = 7680, 4320, 4096, 25.0
-    out["tiled_resolve_8k"], (gb8, out8, lights8, push8) = tiled_line(W8, H8, L8, R8, profiled=True)
+    # Radius cutoff with light lists: the 8K x 4096-light configuration and the two 4K ones on the analytic scene
+    # (coherent depth), and the 8K one again on depth that is uncorrelated between neighbouring pixels.
+    for name in ("tiled_resolve_4k_256", "tiled_resolve_4k_4096", "tiled_resolve_8k_discontinuous"):
+        out[name], keep = tiled_line(ctx, vkr, synth, frame, K, WU, name, pmc)
+        del keep
+    W8, H8, L8, R8 = TILED_WORKLOADS["tiled_resolve_8k"]
+    out["tiled_resolve_8k"], (gb8, out8, lights8, push8) = tiled_line(ctx, vkr, synth, frame, K, WU, "tiled_resolve_8k", pmc)
     if world > 1:  # the same 8K frame in screen bands, one band per rank, gathered on rank 0
         out["tiled_resolve_8k"]["band_sharded"] = band_bench(gb8, out8, lights8, L8, push8, vkr.DEFERRED_RADIUS_CUTOFF, W8, H8)
     del gb8, out8, lights8
@@ -214,7 +251,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cull", action="store_true")
     ap.add_argument("--no-cold", action="store_true", help="skip the run that rotates over four G-buffer sets")
-    ap.add_argument("--tiled-8k-only", action="store_true", help="skip the two 4K radius-cutoff lines (counter passes: keeps the list kernels' per-launch averages to one workload)")
+    ap.add_argument("--only-tiled", choices=sorted(TILED_WORKLOADS), help="run this radius-cutoff workload and nothing else (counter passes: the list kernels' per-launch averages then belong to one workload)")
     ap.add_argument("--no-callers", action="store_true", help="skip the steps either side of the passes (bounds, G-buffer producers, camera path)")
     args = ap.parse_args()
 
@@ -275,6 +312,11 @@ def main():
 
     W, H, L = args.width, args.height, args.lights
     K, WU = args.steps, args.warmup
+    if args.only_tiled:
+        line, _ = tiled_line(ctx, vkr, synth, importlib.import_module("vk-renderer_amd.frame"), K, WU, args.only_tiled, {})
+        if rank == 0:
+            print(json.dumps({args.only_tiled: line}))
+        return
 
     # ---------------------------------------------------------------- deferred: frame per rank
     case = synth.deferred_case(W, H, L, config_index=1 + rank)

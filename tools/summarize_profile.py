@@ -32,6 +32,11 @@ shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 bench_line = [l for l in open(os.path.join(src, "bench_under_trace.log")) if l.startswith("{")]
 if bench_line:
     open(os.path.join(dst, f"{tag}_bench_under_trace.json"), "w").write(bench_line[-1])
+if os.path.isdir(os.path.join(src, "trace_headline")):  # the headline part alone (bench.py --no-callers)
+    shutil.copy(newest(os.path.join(src, "trace_headline", "*", "*kernel_stats.csv")), os.path.join(dst, f"{tag}_kernel_stats_headline.csv"))
+    line = [l for l in open(os.path.join(src, "bench_headline_under_trace.log")) if l.startswith("{")]
+    if line:
+        open(os.path.join(dst, f"{tag}_bench_headline_under_trace.json"), "w").write(line[-1])
 
 out = collections.defaultdict(dict)
 for f in [newest(os.path.join(d, "*", "*counter_collection.csv")) for d in glob.glob(os.path.join(src, "pmc_*")) if os.path.isdir(d)]:
@@ -65,5 +70,24 @@ for k, c in out.items():
         c["l2_hit_rate"] = c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1)
     if "GRBM_GUI_ACTIVE" in c and "pmc_SQ_WAVES" in c.get("duration_us_under_pmc", {}):
         c["clock_GHz_under_pmc"] = c["GRBM_GUI_ACTIVE"] / 8 / (c["duration_us_under_pmc"]["pmc_SQ_WAVES"] * 1e3)
+
+# the radius-cutoff workloads, each profiled alone (bench.py --only-tiled NAME): bytes of one call = sum over its launches
+TILED_KERNELS = ("light_bins_kernel", "tile_lists_kernel", "deferred_list_kernel")
+for d in sorted(glob.glob(os.path.join(src, "wl_*__*"))):
+    if not os.path.isdir(d):
+        continue
+    wl, counter = os.path.basename(d)[3:].split("__")
+    per_kernel = collections.defaultdict(list)
+    for r in csv.DictReader(open(newest(os.path.join(d, "*", "*counter_collection.csv")))):
+        if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in TILED_KERNELS):
+            per_kernel[next(k for k in TILED_KERNELS if k in r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    scale = 2048.0 if counter == "FETCH_SIZE" else 1024.0  # KiB; FETCH_SIZE doubled (see above)
+    w = out[wl]
+    for k, v in per_kernel.items():
+        vv = v[len(v) // 3:]
+        w.setdefault("per_kernel_bytes", {}).setdefault(k, {})["read" if counter == "FETCH_SIZE" else "write"] = sum(vv) / len(vv) * scale
+for wl, w in out.items():
+    if "per_kernel_bytes" in w:
+        w["hbm_traffic_bytes_per_launch"] = sum(sum(k.values()) for k in w["per_kernel_bytes"].values())
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True))

@@ -131,8 +131,45 @@ struct LoopConsts {
   float step_scale, step_bias, dist_floor, radius2_scaled;
 };
 
-template <bool kRadius>
-__device__ __forceinline__ void shade4(Pixel& a, Pixel& b, const Light& A, const Light& B, const LoopConsts& kc) {
+// Wave-uniform state of the "every light of this trip is behind every surface of this wave" test.
+// `budget` trips are still tested without a success; a success refills it.  A wave whose pixels face all ways
+// (normals uncorrelated between neighbours) never succeeds and soon stops paying for the test; a wave over one
+// surface succeeds for every light on the far side of it.  A list starts with a full budget if the wave's previous
+// list ended with budget left, and with a token one otherwise (probe_budget_for).
+struct Probe {
+  uint32_t budget;
+#ifdef VKR_X_COUNT
+  uint32_t skipped = 0;
+#endif
+};
+#ifdef VKR_X_COUNT  // measurement builds only (tools/skip_stats.py): trips walked / skipped by the test / not walked at all (wave-level skip)
+__device__ unsigned long long g_trip_counts[3];
+#define VKR_COUNT_TRIPS(walked, skipped_by_test, not_walked)                                  \
+  if ((threadIdx.x & 63u) == 0u) {                                                            \
+    atomicAdd(&g_trip_counts[0], (unsigned long long)(walked));                               \
+    atomicAdd(&g_trip_counts[1], (unsigned long long)(skipped_by_test));                      \
+    atomicAdd(&g_trip_counts[2], (unsigned long long)(not_walked));                           \
+  }
+#else
+#define VKR_COUNT_TRIPS(walked, skipped_by_test, not_walked)
+#endif
+#ifndef VKR_X_BUDGET
+#define VKR_X_BUDGET 8
+#endif
+constexpr uint32_t kProbeBudget = VKR_X_BUDGET, kProbeBudgetLow = 2;
+// Budget of a list of `trips` trips for a wave whose previous list left `left` (kProbeBudget before its first list).
+__device__ __forceinline__ uint32_t probe_budget_for(uint32_t trips, uint32_t left) {
+  return left == 0u ? kProbeBudgetLow : max(kProbeBudgetLow, min(kProbeBudget, trips / 8u));
+}
+
+// With the test (kProbe) the next trip's light records are requested from LDS inside the trip: the positions right
+// after the test (it ends a basic block, and a request made ahead of it would pin its registers across it; the
+// current positions are dead by then, so the new ones take their registers), the colours after the sums have
+// taken the current ones.  Without the test the caller requests both ahead of the call, where the scheduler is free to
+// place them.
+template <bool kRadius, bool kProbe, class FetchPos, class FetchCol>
+__device__ __forceinline__ void shade4(Pixel& a, Pixel& b, const Light& A, const Light& B, const LoopConsts& kc, Probe& probe, FetchPos&& fetch_next_pos,
+                                       FetchCol&& fetch_next_col) {
   float dll[4], lt[4], lb[4], ln[4], inv[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -145,51 +182,81 @@ __device__ __forceinline__ void shade4(Pixel& a, Pixel& b, const Light& A, const
     ln[k] = fma_(wz, s.nz, fma_(wy, s.ny, wx * s.nx));
   }
   rsq4(inv, dll);
-  float c[4], hh[4], dn[4], att[4], sh[4], qa[4], q[4];
+  float c[4], near[4], wd[4], ws[4], wp[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const Pixel& s = (k & 1) ? b : a;
     c[k] = ln[k] * inv[k];
-    const float ht = fma_(lt[k], inv[k], s.vt);
-    const float hb = fma_(lb[k], inv[k], s.vb);
-    const float hn = c[k] + s.vn;
-    const float ht2 = fma_(hb, hb, ht * ht);
-    const float hn2 = hn * hn;
-    hh[k] = ht2 + hn2;
-    dn[k] = fma_(s.a2, hn2, ht2);
-    att[k] = clamp01_((inv[k] * inv[k]) * kc.dist_floor);  // min(1/d^2, 1e7) * 1e-7
+    if (kRadius) near[k] = clamp01_(fma_(dll[k], -kRadiusStepScale, kc.radius2_scaled));  // 1 iff dist^2 < radius^2
   }
-  sqrt4(sh, hh);
-  float kd[4], pvh[4], den[4], rden[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const Pixel& s = (k & 1) ? b : a;
-    pvh[k] = pow5_(clamp01_(fma_(sh[k], -0.5f, 1.0f)));  // (1 - v.h)^5
-    const float f90m1 = fma_(hh[k], s.rh, s.ebm1);
-    const float pl = pow5_(clamp01_(1.0f - c[k]));
-    kd[k] = fma_(f90m1, pl, 1.0f) * fma_(f90m1, s.pv, 1.0f);
-    qa[k] = fma_(s.a2, c[k] * c[k], 1.0f);
+  bool skip = false;  // wave-uniform
+  if (kProbe) {
+    // deferred.comp:43,84 return 0 for l.n <= 1e-6.  When that holds for all four pairs of every lane, with every
+    // cosine a number in [-2, -0] (as a signed integer the bit pattern of such a float is <= 0xC0000000; the
+    // patterns of NaN, of -inf and of anything positive are greater), the step multiplier below is 0 and every other
+    // factor is finite (positions, frames and 1/d are, or the cosine would not be a number of that size), so each of
+    // the twelve weights is +-0: the three remaining groups of transcendentals and the arithmetic between them are
+    // skipped and the weights set to 0.  The sums still take colour * 0 (a colour that is not finite makes that NaN,
+    // as it does on the long way round).
+    const int m01 = max(__float_as_int(c[0]), __float_as_int(c[1])), m23 = max(__float_as_int(c[2]), __float_as_int(c[3]));
+    const bool behind = max(m01, m23) <= (int)0xC0000000;
+    skip = __ballot(!behind) == 0ull;
+    probe.budget = skip ? kProbeBudget : probe.budget - 1u;
+#ifdef VKR_X_COUNT
+    probe.skipped += skip ? 1u : 0u;
+#endif
+    fetch_next_pos();
   }
-  sqrt4(q, qa);
+  if (skip) {
+    // as instructions of this branch: plain assignments are hoisted above the test, into every trip
 #pragma unroll
-  for (int k = 0; k < 4; ++k) den[k] = fma_(dn[k] * dn[k], c[k] + q[k], 1e-37f);  // +1e-37 keeps culled lanes finite
-  rcp4(rden, den);
-  float wd[4], ws[4], wp[4];
+    for (int k = 0; k < 4; ++k) asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0" : "=v"(wd[k]), "=v"(ws[k]), "=v"(wp[k]));
+  } else {
+    float hh[4], dn[4], att[4], sh[4], qa[4], q[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    // early-out of deferred.comp:43,84 as a multiplier: (c - 1e-6) * 2^100 is exact inside the FMA; its clamp
-    // is 1 for every c > 1e-6 and 0 for c <= 1e-6 or NaN
-    float ci = (c[k] * clamp01_(fma_(c[k], kc.step_scale, kc.step_bias))) * att[k];
-    if (kRadius) {
-      const float near = clamp01_(fma_(dll[k], -kRadiusStepScale, kc.radius2_scaled));  // 1 iff dist^2 < radius^2
-      ci *= near;
-      Pixel& s = (k & 1) ? b : a;
-      s.in_range += near;
+    for (int k = 0; k < 4; ++k) {
+      const Pixel& s = (k & 1) ? b : a;
+      const float ht = fma_(lt[k], inv[k], s.vt);
+      const float hb = fma_(lb[k], inv[k], s.vb);
+      const float hn = c[k] + s.vn;
+      const float ht2 = fma_(hb, hb, ht * ht);
+      const float hn2 = hn * hn;
+      hh[k] = ht2 + hn2;
+      dn[k] = fma_(s.a2, hn2, ht2);
+      att[k] = clamp01_((inv[k] * inv[k]) * kc.dist_floor);  // min(1/d^2, 1e7) * 1e-7
     }
-    const float ks0 = (hh[k] * hh[k]) * rden[k];
-    wd[k] = kd[k] * ci;
-    ws[k] = ks0 * ci;
-    wp[k] = ws[k] * pvh[k];
+    sqrt4(sh, hh);
+    float kd[4], pvh[4], den[4], rden[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const Pixel& s = (k & 1) ? b : a;
+      pvh[k] = pow5_(clamp01_(fma_(sh[k], -0.5f, 1.0f)));  // (1 - v.h)^5
+      const float f90m1 = fma_(hh[k], s.rh, s.ebm1);
+      const float pl = pow5_(clamp01_(1.0f - c[k]));
+      kd[k] = fma_(f90m1, pl, 1.0f) * fma_(f90m1, s.pv, 1.0f);
+      qa[k] = fma_(s.a2, c[k] * c[k], 1.0f);
+    }
+    sqrt4(q, qa);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) den[k] = fma_(dn[k] * dn[k], c[k] + q[k], 1e-37f);  // +1e-37 keeps culled lanes finite
+    rcp4(rden, den);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      // early-out of deferred.comp:43,84 as a multiplier: (c - 1e-6) * 2^100 is exact inside the FMA; its clamp
+      // is 1 for every c > 1e-6 and 0 for c <= 1e-6 or NaN
+      float ci = (c[k] * clamp01_(fma_(c[k], kc.step_scale, kc.step_bias))) * att[k];
+      if (kRadius) ci *= near[k];
+      const float ks0 = (hh[k] * hh[k]) * rden[k];
+      wd[k] = kd[k] * ci;
+      ws[k] = ks0 * ci;
+      wp[k] = ws[k] * pvh[k];
+    }
+  }
+  if (kRadius) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      Pixel& s = (k & 1) ? b : a;
+      s.in_range += near[k];
+    }
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -205,6 +272,7 @@ __device__ __forceinline__ void shade4(Pixel& a, Pixel& b, const Light& A, const
     s.as1[1] = fma_(l.cy, wp[k], s.as1[1]);
     s.as1[2] = fma_(l.cz, wp[k], s.as1[2]);
   }
+  if (kProbe) fetch_next_col();
 }
 
 // deferred.comp:99-100: clip-space coordinate of a pixel centre, true division included.
@@ -385,7 +453,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void deferred_kernel(const Deferred
   constexpr uint32_t kThreads = 64u * kWaves, kTileRows = 8u * kWaves, kLightChunk = 128u * kWaves;
   static_assert(kLightChunk <= (uint32_t)kChunk, "chunk beyond the staging area's size");
   __shared__ float4 s_light[2 * kLightChunk + 4];  // +1 pair: the prefetch of the last iteration reads past the list
-  __shared__ uint32_t s_stash[14][kThreads];  // rows: see kRow* below
+  __shared__ uint32_t s_stash[12][kThreads];  // rows: see kRow* below
   constexpr bool kIs8Bit = kOutMode == kOutRgba8 || kOutMode == kOutBgra8;
   const uint32_t t = threadIdx.x;
   const float4* __restrict__ lights = reinterpret_cast<const float4*>(p.lights);
@@ -399,17 +467,30 @@ __global__ __launch_bounds__(64 * kWaves, 4) void deferred_kernel(const Deferred
 
   const uint32_t tile_x = blockIdx.x, tile_y = blockIdx.y;
   const uint32_t count = L;  // lights this tile walks
-  const uint32_t x0 = tile_x * 32u + (t & 7u) * 4u;
-  const uint32_t y = tile_y * kTileRows + (t >> 3);
-  const bool inside = (x0 < p.width) && (y < p.height);
-  // lanes outside the image shade the tile's first group (in bounds by construction) and store nothing
-  const uint32_t lx = inside ? x0 : tile_x * 32u;
-  const uint32_t ly = inside ? y : tile_y * kTileRows;
-  const uint32_t y_full = ly + p.row_offset;
+  // Where a lane's four pixels are.  Derived from the thread index wherever it is needed (through a copy the
+  // compiler cannot see through) rather than kept: the light loop leaves no register for values that merely wait.
+  struct Where {
+    uint32_t x0, y, lx, ly;
+    bool inside;
+  };
+  auto where = [&](uint32_t tq) {
+    uint32_t ox = tile_x * 32u, oy = tile_y * kTileRows;  // uniform; opaque too, or their vector-register copies wait across the loop
+    asm volatile("" : "+v"(tq), "+s"(ox), "+s"(oy));
+    Where w;
+    w.x0 = ox + (tq & 7u) * 4u;
+    w.y = oy + (tq >> 3);
+    w.inside = (w.x0 < p.width) && (w.y < p.height);
+    // lanes outside the image shade the tile's first group (in bounds by construction) and store nothing
+    w.lx = w.inside ? w.x0 : ox;
+    w.ly = w.inside ? w.y : oy;
+    return w;
+  };
+  const Where w0 = where(t);
+  const uint32_t lx = w0.lx, ly = w0.ly;
+  const bool inside = w0.inside;
 
   const uint4 alb4 = *reinterpret_cast<const uint4*>(p.albedo + (size_t)ly * p.pitch_albedo + (size_t)lx * 4u);
   const uint4 mat4 = *reinterpret_cast<const uint4*>(p.material + (size_t)ly * p.pitch_material + (size_t)lx * 4u);
-  const float4 dep4 = *reinterpret_cast<const float4*>(p.depth + (size_t)ly * p.pitch_depth + (size_t)lx * 4u);
   const uint4 nrmA = *reinterpret_cast<const uint4*>(p.normal + (size_t)ly * p.pitch_normal + (size_t)lx * 8u);
   const uint4 nrmB = *reinterpret_cast<const uint4*>(p.normal + (size_t)ly * p.pitch_normal + (size_t)lx * 8u + 16u);
 
@@ -419,12 +500,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void deferred_kernel(const Deferred
   // the lane: no barrier needed).  Left in VGPRs, the register allocator spills part of them to scratch
   // memory, which is HBM traffic of the order of the output itself.  The rows are kept few: past
   // 32 KiB of LDS per workgroup the kernel measurably slows down.
-  enum { kRowAlbedo = 0, kRowMaterial = 4, kRowNormal = 8, kRowExtra = 12, kStashRows = 14 };
-  const ExactRcp by_width = exact_rcp((float)p.width), by_height = exact_rcp((float)p.full_height);
-  const float cy = clip_coord(y_full, by_height);
-  float cx[2] = {clip_coord(lx, by_width), clip_coord(lx + 1u, by_width)};
-  const float cx_next[2] = {clip_coord(lx + 2u, by_width), clip_coord(lx + 3u, by_width)};
-  float dep[2] = {dep4.x, dep4.y};
+  enum { kRowAlbedo = 0, kRowMaterial = 4, kRowNormal = 8, kStashRows = 12 };
   uint32_t mat[2] = {mat4.x, mat4.y};
   uint32_t nlo[2] = {nrmA.x, nrmA.z};
   uint32_t nhi[2] = {nrmA.y, nrmA.w};
@@ -442,23 +518,8 @@ __global__ __launch_bounds__(64 * kWaves, 4) void deferred_kernel(const Deferred
   s_stash[kRowNormal + 3][t] = nrmB.w;
 
   const bool wave_live = __ballot(inside) != 0ull;  // wave-uniform
-  float last[2][3] = {};  // float outputs: the second pair's colours
 
-  // results: the first pair's go to LDS (over the rows of the words just consumed) until the second
-  // pair is done, so that each lane writes its four pixels with full-width stores
-  auto keep_result = [&](int g, int i, const float (&rgb)[3]) {
-    if (kIs8Bit) {
-      s_stash[kRowAlbedo + g + i][t] = pack_unorm8<kOutMode>(rgb);
-    } else if (g == 0) {
-      s_stash[kRowAlbedo + i][t] = __float_as_uint(rgb[0]);
-      s_stash[kRowMaterial + i][t] = __float_as_uint(rgb[1]);
-      s_stash[kRowExtra + i][t] = __float_as_uint(rgb[2]);
-    } else {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) last[i][k] = rgb[k];
-    }
-  };
-
+  uint32_t probe_left = kProbeBudget;  // wave-uniform: what the wave's previous list left of its test budget
   // One copy of the light loop serves both pixel pairs (no unrolling): half the code, same speed.
 #pragma unroll 1
   for (int g = 0; g < 4; g += 2) {
@@ -466,34 +527,67 @@ __global__ __launch_bounds__(64 * kWaves, 4) void deferred_kernel(const Deferred
     if (g != 0) {
       mat[0] = s_stash[kRowMaterial + 2][t];
       mat[1] = s_stash[kRowMaterial + 3][t];
-      dep[0] = dep4.z;
-      dep[1] = dep4.w;
       nlo[0] = s_stash[kRowNormal + 0][t];
       nhi[0] = s_stash[kRowNormal + 1][t];
       nlo[1] = s_stash[kRowNormal + 2][t];
       nhi[1] = s_stash[kRowNormal + 3][t];
-      cx[0] = cx_next[0];
-      cx[1] = cx_next[1];
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) setup_pixel(s[i], p, cx[i], cy, dep[i], mat[i], nlo[i], nhi[i]);
+    {
+      const Where w = where(t);
+      // uniform values taken through copies the compiler cannot see through, so that they are fetched or derived
+      // here and not kept in vector registers from before the light loop
+      const uint8_t* depth = p.depth;
+      uint32_t width = p.width, full_height = p.full_height;
+      asm volatile("" : "+s"(depth), "+s"(width), "+s"(full_height));
+      const float2 dep = *reinterpret_cast<const float2*>(depth + (size_t)w.ly * p.pitch_depth + (size_t)(w.lx + (uint32_t)g) * 4u);
+      const ExactRcp by_width = exact_rcp((float)width), by_height = exact_rcp((float)full_height);
+      const float cy = clip_coord(w.ly + p.row_offset, by_height);
+      setup_pixel(s[0], p, clip_coord(w.lx + (uint32_t)g, by_width), cy, dep.x, mat[0], nlo[0], nhi[0]);
+      setup_pixel(s[1], p, clip_coord(w.lx + (uint32_t)g + 1u, by_width), cy, dep.y, mat[1], nlo[1], nhi[1]);
+    }
 
     // shades the first `n` records of s_light (n even, > 0)
     auto shade_list = [&](uint32_t n) {
       const float4* rec = s_light;
       float4 pa = rec[0], ca = rec[1], pb = rec[2], cb = rec[3];
-      for (uint32_t j = 0; j < n; j += 2u) {
+      Probe probe{probe_budget_for(n / 2u, probe_left)};
+      // Two copies of the loop: trips are tested for "every light behind every surface of the wave" while the
+      // budget lasts, and the rest of the list runs through the loop without the test, which is the faster one per
+      // trip (the test ends a basic block in the middle of the trip, and the register allocator pays for that
+      // with copies).  The second loop starts from LDS again, so that nothing but the pixels ties the two together.
+      uint32_t j = 0;
+      for (; j < n && probe.budget != 0u; j += 2u) {
         const Light A{pa.x, pa.y, pa.z, ca.x, ca.y, ca.z};
         const Light B{pb.x, pb.y, pb.z, cb.x, cb.y, cb.z};
         rec += 4;  // next pair (one pair beyond the list on the last trip: read, never used)
-        pa = rec[0];
-        ca = rec[1];
-        pb = rec[2];
-        cb = rec[3];
-        shade4<kRadius>(s[0], s[1], A, B, kc);
+        shade4<kRadius, true>(
+            s[0], s[1], A, B, kc, probe, [&] { pa = rec[0], pb = rec[2]; }, [&] { ca = rec[1], cb = rec[3]; });
       }
+      if (j < n) {
+        const float4* rec2 = s_light + 2u * j;
+        float4 pa2 = rec2[0], ca2 = rec2[1], pb2 = rec2[2], cb2 = rec2[3];
+        for (; j < n; j += 2u) {
+          const Light A{pa2.x, pa2.y, pa2.z, ca2.x, ca2.y, ca2.z};
+          const Light B{pb2.x, pb2.y, pb2.z, cb2.x, cb2.y, cb2.z};
+          rec2 += 4;
+          pa2 = rec2[0];
+          ca2 = rec2[1];
+          pb2 = rec2[2];
+          cb2 = rec2[3];
+          shade4<kRadius, false>(s[0], s[1], A, B, kc, probe, [] {}, [] {});
+        }
+      }
+      probe_left = probe.budget;
+#ifdef VKR_X_COUNT
+      VKR_COUNT_TRIPS(n / 2u, probe.skipped, 0u);
+#endif
     };
     const float4 black_pos = make_float4(0.0f, 0.0f, 1e18f, 0.0f), black_col = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    // deferred.comp:43,84: a pixel with v.n <= 1e-6 gets 0 from every light, and one whose v.n is not a number comes
+    // out NaN whatever the loop computes (finish_pixel) - with the radius cutoff only if a light lay in range, which
+    // the loop finds out.  A wave none of whose pixels the loop can change does not walk the table.
+    const bool lane_lit = kRadius ? (!(s[0].vn <= kEarlyOut) || !(s[1].vn <= kEarlyOut)) : (s[0].vn > kEarlyOut || s[1].vn > kEarlyOut);
+    const bool wave_lit = wave_live && __ballot(lane_lit) != 0ull;  // wave-uniform
 
     for (uint32_t base = 0; base < count; base += kLightChunk) {
       const uint32_t n = min(kLightChunk, count - base);
@@ -509,34 +603,50 @@ __global__ __launch_bounds__(64 * kWaves, 4) void deferred_kernel(const Deferred
         s_light[2u * i + 1u] = lc;
       }
       __syncthreads();
-      if (wave_live) shade_list(n2);
+      if (wave_lit) {
+        shade_list(n2);
+      } else if (wave_live) {
+        VKR_COUNT_TRIPS(n2 / 2u, 0u, n2 / 2u);
+      }
     }
+    float rgb[2][3];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      float rgb[3];
-      finish_pixel(s[i], s_stash[kRowAlbedo + g + i][t], s_stash[kRowMaterial + g + i][t], kRadius ? s[i].in_range > 0.0f : L > 0u, rgb);
-      keep_result(g, i, rgb);
+    for (int i = 0; i < 2; ++i)
+      finish_pixel(s[i], s_stash[kRowAlbedo + g + i][t], s_stash[kRowMaterial + g + i][t], kRadius ? s[i].in_range > 0.0f : L > 0u, rgb[i]);
+    if (kIs8Bit) {
+      // 8-bit results wait in LDS (over the rows of the albedo words just consumed) until the second pair is
+      // done, so that each lane writes its four pixels with one full-width store
+#pragma unroll
+      for (int i = 0; i < 2; ++i) s_stash[kRowAlbedo + g + i][t] = pack_unorm8<kOutMode>(rgb[i]);
+    } else {
+      // float texels are 8 or 16 bytes: a pair is a full-width store (or two) by itself
+      const Where w = where(t);
+      if (w.inside) {
+        const uint32_t xg = w.x0 + (uint32_t)g;
+        uint8_t* orow = p.out + (size_t)w.y * p.pitch_out;
+        const bool first = xg < p.width, second = xg + 1u < p.width;
+        if (kOutMode == kOutRgba16f) {
+          uint2* o = reinterpret_cast<uint2*>(orow) + xg;
+          const uint2 t0 = half_texel(rgb[0][0], rgb[0][1], rgb[0][2]), t1 = half_texel(rgb[1][0], rgb[1][1], rgb[1][2]);
+          if (second)
+            *reinterpret_cast<uint4*>(o) = make_uint4(t0.x, t0.y, t1.x, t1.y);
+          else if (first)
+            o[0] = t0;
+        } else {
+          float4* o = reinterpret_cast<float4*>(orow) + xg;
+          if (first) o[0] = make_float4(rgb[0][0], rgb[0][1], rgb[0][2], 1.0f);
+          if (second) o[1] = make_float4(rgb[1][0], rgb[1][1], rgb[1][2], 1.0f);
+        }
+      }
     }
   }
-  if (inside) {
-    const uint32_t valid = min(4u, p.width - x0);
-    uint8_t* orow = p.out + (size_t)y * p.pitch_out;
-    if (kIs8Bit) {
+  if (kIs8Bit) {
+    const Where w1 = where(t);
+    if (w1.inside) {
       uint32_t packed[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) packed[i] = s_stash[kRowAlbedo + i][t];
-      store_rgba8x4(orow, x0, valid, packed);
-    } else {
-      float rgb[4][3];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const int row = k == 0 ? kRowAlbedo : k == 1 ? kRowMaterial : kRowExtra;
-          rgb[i][k] = __uint_as_float(s_stash[row + i][t]);
-          rgb[2 + i][k] = last[i][k];
-        }
-      store_float4x4<kOutMode>(orow, x0, valid, rgb);
+      store_rgba8x4(p.out + (size_t)w1.y * p.pitch_out, w1.x0, min(4u, p.width - w1.x0), packed);
     }
   }
 }
@@ -564,6 +674,7 @@ constexpr uint32_t kStripRows = 4, kStripsPerTile = 32 / kStripRows, kWaveChunk 
 template <int kOutMode>
 __global__ __launch_bounds__(64, 4) void deferred_list_kernel(const DeferredParams p) {
   __shared__ float4 s_light[2 * kWaveChunk + 4];  // +1 pair: the prefetch of the last iteration reads past the list
+  __shared__ uint32_t s_keep[4][64];
   constexpr bool kIs8Bit = kOutMode == kOutRgba8 || kOutMode == kOutBgra8;
   const uint32_t t = threadIdx.x;
   const float4* __restrict__ lights = reinterpret_cast<const float4*>(p.lights);
@@ -609,13 +720,27 @@ __global__ __launch_bounds__(64, 4) void deferred_list_kernel(const DeferredPara
         count = word;
       }
     }
-    const uint32_t x0 = tile_x * 32u + (t & 15u) * 2u;
-    const uint32_t y = tile_y * 32u + strip * kStripRows + (t >> 4);
-    const bool inside = (x0 < p.width) && (y < p.height);
-    if (__ballot(inside) == 0ull) continue;  // a strip below the image's last row (wave-uniform)
-    // lanes outside the image shade the tile's first pair (in bounds by construction) and store nothing
-    const uint32_t lx = inside ? x0 : tile_x * 32u;
-    const uint32_t ly = inside ? y : tile_y * 32u;
+    // Where the lane's two pixels are: derived from the thread index where needed (through a copy the compiler
+    // cannot see through) rather than kept across the light loop, which leaves no register for values that wait.
+    struct Where {
+      uint32_t x0, y, lx, ly;
+      bool inside;
+    };
+    auto where = [&](uint32_t tq) {
+      uint32_t ox = tile_x * 32u, oy = tile_y * 32u, oys = tile_y * 32u + strip * kStripRows;
+      asm volatile("" : "+v"(tq), "+s"(ox), "+s"(oy), "+s"(oys));
+      Where w;
+      w.x0 = ox + (tq & 15u) * 2u;
+      w.y = oys + (tq >> 4);
+      w.inside = (w.x0 < p.width) && (w.y < p.height);
+      // lanes outside the image shade the tile's first pair (in bounds by construction) and store nothing
+      w.lx = w.inside ? w.x0 : ox;
+      w.ly = w.inside ? w.y : oy;
+      return w;
+    };
+    const Where w0 = where(t);
+    if (__ballot(w0.inside) == 0ull) continue;  // a strip below the image's last row (wave-uniform)
+    const uint32_t lx = w0.lx, ly = w0.ly;
     const uint2 alb2 = *reinterpret_cast<const uint2*>(p.albedo + (size_t)ly * p.pitch_albedo + (size_t)lx * 4u);
     const uint2 mat2 = *reinterpret_cast<const uint2*>(p.material + (size_t)ly * p.pitch_material + (size_t)lx * 4u);
     const float2 dep2 = *reinterpret_cast<const float2*>(p.depth + (size_t)ly * p.pitch_depth + (size_t)lx * 4u);
@@ -634,12 +759,26 @@ __global__ __launch_bounds__(64, 4) void deferred_list_kernel(const DeferredPara
     };
     float4 lp, lc;
     fetch_chunk(0u, lp, lc);
-    const ExactRcp by_width = exact_rcp((float)p.width), by_height = exact_rcp((float)p.full_height);
+    uint32_t width = p.width, full_height = p.full_height;
+    asm volatile("" : "+s"(width), "+s"(full_height));  // their reciprocals are derived per unit, not kept in vector registers
+    const ExactRcp by_width = exact_rcp((float)width), by_height = exact_rcp((float)full_height);
     const float cy = clip_coord(ly + p.row_offset, by_height);
     Pixel s[2];
     setup_pixel(s[0], p, clip_coord(lx, by_width), cy, dep2.x, mat2.x, nrm.x, nrm.y);
     setup_pixel(s[1], p, clip_coord(lx + 1u, by_width), cy, dep2.y, mat2.y, nrm.z, nrm.w);
+    // the albedo and material words are decoded after the loop: they wait in LDS, one column per lane
+    s_keep[0][t] = alb2.x;
+    s_keep[1][t] = alb2.y;
+    s_keep[2][t] = mat2.x;
+    s_keep[3][t] = mat2.y;
 
+    uint32_t probe_left = kProbeBudget;
+    // a wave whose pixels all have a v.n that is a number <= 1e-6 gets 0 from every light (deferred.comp:43,84) and
+    // does not need to know whether one lay in range: it keeps its ambient colour either way
+    if (__ballot(!(s[0].vn <= kEarlyOut) || !(s[1].vn <= kEarlyOut)) == 0ull) {
+      VKR_COUNT_TRIPS((count + 1u) / 2u, 0u, (count + 1u) / 2u);
+      count = 0u;
+    }
     for (uint32_t base = 0; base < count; base += kWaveChunk) {
       const uint32_t n = min(kWaveChunk, count - base);
       const uint32_t n2 = (n + 1u) & ~1u;
@@ -647,29 +786,48 @@ __global__ __launch_bounds__(64, 4) void deferred_list_kernel(const DeferredPara
       // the previous chunk and these writes
       s_light[2u * t] = lp;
       s_light[2u * t + 1u] = lc;
+      Probe probe{probe_budget_for(n2 / 2u, probe_left)};
       if (base + kWaveChunk < count) fetch_chunk(base + kWaveChunk, lp, lc);  // the next chunk, while this one is shaded
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const float4* rec = s_light;
       float4 pa = rec[0], ca = rec[1], pb = rec[2], cb = rec[3];
-      for (uint32_t j = 0; j < n2; j += 2u) {
+      uint32_t j = 0;
+      for (; j < n2 && probe.budget != 0u; j += 2u) {  // see deferred_kernel: the loop with the test, then the one without
         const Light A{pa.x, pa.y, pa.z, ca.x, ca.y, ca.z};
         const Light B{pb.x, pb.y, pb.z, cb.x, cb.y, cb.z};
         rec += 4;  // next pair (one pair beyond the list on the last trip: read, never used)
-        pa = rec[0];
-        ca = rec[1];
-        pb = rec[2];
-        cb = rec[3];
-        shade4<true>(s[0], s[1], A, B, kc);
+        shade4<true, true>(
+            s[0], s[1], A, B, kc, probe, [&] { pa = rec[0], pb = rec[2]; }, [&] { ca = rec[1], cb = rec[3]; });
       }
+      if (j < n2) {
+        const float4* rec2 = s_light + 2u * j;
+        float4 pa2 = rec2[0], ca2 = rec2[1], pb2 = rec2[2], cb2 = rec2[3];
+        for (; j < n2; j += 2u) {
+          const Light A{pa2.x, pa2.y, pa2.z, ca2.x, ca2.y, ca2.z};
+          const Light B{pb2.x, pb2.y, pb2.z, cb2.x, cb2.y, cb2.z};
+          rec2 += 4;
+          pa2 = rec2[0];
+          ca2 = rec2[1];
+          pb2 = rec2[2];
+          cb2 = rec2[3];
+          shade4<true, false>(s[0], s[1], A, B, kc, probe, [] {}, [] {});
+        }
+      }
+      probe_left = probe.budget;
+#ifdef VKR_X_COUNT
+      VKR_COUNT_TRIPS(n2 / 2u, probe.skipped, 0u);
+#endif
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
     float rgb[2][3];
-    finish_pixel(s[0], alb2.x, mat2.x, s[0].in_range > 0.0f, rgb[0]);
-    finish_pixel(s[1], alb2.y, mat2.y, s[1].in_range > 0.0f, rgb[1]);
-    if (inside) {
+    finish_pixel(s[0], s_keep[0][t], s_keep[2][t], s[0].in_range > 0.0f, rgb[0]);
+    finish_pixel(s[1], s_keep[1][t], s_keep[3][t], s[1].in_range > 0.0f, rgb[1]);
+    const Where w1 = where(t);
+    if (w1.inside) {
+      const uint32_t x0 = w1.x0, y = w1.y;
       const bool both = x0 + 1u < p.width;
       uint8_t* orow = p.out + (size_t)y * p.pitch_out;
       if (kIs8Bit) {
@@ -1069,6 +1227,17 @@ hipError_t launch_mode(const DeferredParams& p, const TileListOut* lists, uint32
 }
 
 }  // namespace
+
+#ifdef VKR_X_COUNT
+extern "C" __attribute__((visibility("default"))) int vkr_x_trip_counts(unsigned long long out[3], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trip_counts), sizeof(g_trip_counts)) != hipSuccess) return 1;
+  if (reset) {
+    const unsigned long long zero[3] = {0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_trip_counts), zero, sizeof(zero)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
 
 hipError_t vkr_launch_exact_div_check(uint32_t n, uint32_t seed, uint32_t* mismatches, hipStream_t stream) {
   hipLaunchKernelGGL(exact_div_check_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, n, seed, mismatches);
