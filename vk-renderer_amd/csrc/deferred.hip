@@ -142,6 +142,9 @@ struct Probe {
   uint32_t skipped = 0;
 #endif
 };
+#ifdef VKR_X_TIMES  // measurement builds only (tools/wave_times.py): when each wave of the whole-table kernel started and ended, and where it ran
+__device__ unsigned long long g_wave_times[4 * 65536];
+#endif
 #ifdef VKR_X_COUNT  // measurement builds only (tools/skip_stats.py): trips walked / skipped by the test / not walked at all (wave-level skip)
 __device__ unsigned long long g_trip_counts[3];
 #define VKR_COUNT_TRIPS(walked, skipped_by_test, not_walked)                                  \
@@ -161,20 +164,23 @@ constexpr uint32_t kProbeBudget = VKR_X_BUDGET, kProbeBudgetLow = 2;
 __device__ __forceinline__ uint32_t probe_budget_for(uint32_t trips, uint32_t left) {
   return left == 0u ? kProbeBudgetLow : max(kProbeBudgetLow, min(kProbeBudget, trips / 8u));
 }
-
 // With the test (kProbe) the next trip's light records are requested from LDS inside the trip: the positions right
 // after the test (it ends a basic block, and a request made ahead of it would pin its registers across it; the
 // current positions are dead by then, so the new ones take their registers), the colours after the sums have
 // taken the current ones.  Without the test the caller requests both ahead of the call, where the scheduler is free to
 // place them.
-template <bool kRadius, bool kProbe, class FetchPos, class FetchCol>
-__device__ __forceinline__ void shade4(Pixel& a, Pixel& b, const Light& A, const Light& B, const LoopConsts& kc, Probe& probe, FetchPos&& fetch_next_pos,
+// The four (pixel, light) pairs of a trip are two lights on two pixels (kLights = 2: pairs k = 0..3 are (a,L0) (b,L0)
+// (a,L1) (b,L1)) or four lights on one pixel (kLights = 4: (a,L0) .. (a,L3); b is a).  Either way a pixel's sums take
+// its lights in table order.
+template <bool kRadius, bool kProbe, int kLights, class FetchPos, class FetchCol>
+__device__ __forceinline__ void shade4(Pixel& a, Pixel& b, const Light (&L)[kLights], const LoopConsts& kc, Probe& probe, FetchPos&& fetch_next_pos,
                                        FetchCol&& fetch_next_col) {
+  static_assert(kLights == 2 || kLights == 4, "two lights on two pixels, or four on one");
   float dll[4], lt[4], lb[4], ln[4], inv[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const Pixel& s = (k & 1) ? b : a;
-    const Light& l = (k & 2) ? B : A;
+    const Pixel& s = (kLights == 2 && (k & 1)) ? b : a;
+    const Light& l = L[kLights == 2 ? (k >> 1) : k];
     const float wx = l.px - s.px, wy = l.py - s.py, wz = l.pz - s.pz;
     dll[k] = fma_(wz, wz, fma_(wy, wy, wx * wx));
     lt[k] = fma_(wz, s.tz, fma_(wy, s.ty, wx * s.tx));
@@ -214,7 +220,7 @@ __device__ __forceinline__ void shade4(Pixel& a, Pixel& b, const Light& A, const
     float hh[4], dn[4], att[4], sh[4], qa[4], q[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const Pixel& s = (k & 1) ? b : a;
+      const Pixel& s = (kLights == 2 && (k & 1)) ? b : a;
       const float ht = fma_(lt[k], inv[k], s.vt);
       const float hb = fma_(lb[k], inv[k], s.vb);
       const float hn = c[k] + s.vn;
@@ -228,7 +234,7 @@ __device__ __forceinline__ void shade4(Pixel& a, Pixel& b, const Light& A, const
     float kd[4], pvh[4], den[4], rden[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const Pixel& s = (k & 1) ? b : a;
+      const Pixel& s = (kLights == 2 && (k & 1)) ? b : a;
       pvh[k] = pow5_(clamp01_(fma_(sh[k], -0.5f, 1.0f)));  // (1 - v.h)^5
       const float f90m1 = fma_(hh[k], s.rh, s.ebm1);
       const float pl = pow5_(clamp01_(1.0f - c[k]));
@@ -254,14 +260,14 @@ __device__ __forceinline__ void shade4(Pixel& a, Pixel& b, const Light& A, const
   if (kRadius) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      Pixel& s = (k & 1) ? b : a;
+      Pixel& s = (kLights == 2 && (k & 1)) ? b : a;
       s.in_range += near[k];
     }
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    Pixel& s = (k & 1) ? b : a;
-    const Light& l = (k & 2) ? B : A;
+    Pixel& s = (kLights == 2 && (k & 1)) ? b : a;
+    const Light& l = L[kLights == 2 ? (k >> 1) : k];
     s.ad[0] = fma_(l.cx, wd[k], s.ad[0]);
     s.ad[1] = fma_(l.cy, wd[k], s.ad[1]);
     s.ad[2] = fma_(l.cz, wd[k], s.ad[2]);
@@ -444,10 +450,8 @@ __device__ __forceinline__ void store_float4x4(uint8_t* orow, uint32_t x0, uint3
 // launch bound: 4 waves per SIMD (<= 128 VGPRs); measured 1-2 % faster than the 3 waves the allocator
 // settles on unprompted.
 // kWaves = waves per workgroup: the tile is 32 x (8 * kWaves) pixels and the LDS chunk 128 * kWaves lights.  Four
-// waves (32 x 32) is the form for whole frames; single-wave workgroups are for launches of a few rounds of
-// workgroups only (a screen band of a frame split over several GPUs: 270 rows of a 4K frame are 1080 four-wave
-// workgroups on 1024 slots, i.e. one round and a second one for the last 56, 0.40 ms where an eighth of the
-// whole frame's time is 0.30 ms), where a four times finer grain keeps the last round full.
+// waves (32 x 32) is the form in use, for launches of many rounds of workgroups; short launches (a screen band of a
+// frame split over several GPUs, a 1080p frame) go to deferred_pixel_kernel below.
 template <int kOutMode, bool kRadius, int kWaves>
 __global__ __launch_bounds__(64 * kWaves, 4) void deferred_kernel(const DeferredParams p) {
   constexpr uint32_t kThreads = 64u * kWaves, kTileRows = 8u * kWaves, kLightChunk = 128u * kWaves;
@@ -465,6 +469,10 @@ __global__ __launch_bounds__(64 * kWaves, 4) void deferred_kernel(const Deferred
   asm volatile("v_mov_b32 %0, %1" : "=v"(kc.dist_floor) : "s"(kDistFloor));
   asm volatile("v_mov_b32 %0, %1" : "=v"(kc.radius2_scaled) : "s"(p.radius2 * kRadiusStepScale));
 
+#ifdef VKR_X_TIMES
+  const unsigned long long t_start = __builtin_readcyclecounter();
+  const unsigned long long rt_start = wall_clock64();
+#endif
   const uint32_t tile_x = blockIdx.x, tile_y = blockIdx.y;
   const uint32_t count = L;  // lights this tile walks
   // Where a lane's four pixels are.  Derived from the thread index wherever it is needed (through a copy the
@@ -557,24 +565,22 @@ __global__ __launch_bounds__(64 * kWaves, 4) void deferred_kernel(const Deferred
       // with copies).  The second loop starts from LDS again, so that nothing but the pixels ties the two together.
       uint32_t j = 0;
       for (; j < n && probe.budget != 0u; j += 2u) {
-        const Light A{pa.x, pa.y, pa.z, ca.x, ca.y, ca.z};
-        const Light B{pb.x, pb.y, pb.z, cb.x, cb.y, cb.z};
+        const Light AB[2] = {{pa.x, pa.y, pa.z, ca.x, ca.y, ca.z}, {pb.x, pb.y, pb.z, cb.x, cb.y, cb.z}};
         rec += 4;  // next pair (one pair beyond the list on the last trip: read, never used)
         shade4<kRadius, true>(
-            s[0], s[1], A, B, kc, probe, [&] { pa = rec[0], pb = rec[2]; }, [&] { ca = rec[1], cb = rec[3]; });
+            s[0], s[1], AB, kc, probe, [&] { pa = rec[0], pb = rec[2]; }, [&] { ca = rec[1], cb = rec[3]; });
       }
       if (j < n) {
         const float4* rec2 = s_light + 2u * j;
         float4 pa2 = rec2[0], ca2 = rec2[1], pb2 = rec2[2], cb2 = rec2[3];
         for (; j < n; j += 2u) {
-          const Light A{pa2.x, pa2.y, pa2.z, ca2.x, ca2.y, ca2.z};
-          const Light B{pb2.x, pb2.y, pb2.z, cb2.x, cb2.y, cb2.z};
+          const Light AB[2] = {{pa2.x, pa2.y, pa2.z, ca2.x, ca2.y, ca2.z}, {pb2.x, pb2.y, pb2.z, cb2.x, cb2.y, cb2.z}};
           rec2 += 4;
           pa2 = rec2[0];
           ca2 = rec2[1];
           pb2 = rec2[2];
           cb2 = rec2[3];
-          shade4<kRadius, false>(s[0], s[1], A, B, kc, probe, [] {}, [] {});
+          shade4<kRadius, false>(s[0], s[1], AB, kc, probe, [] {}, [] {});
         }
       }
       probe_left = probe.budget;
@@ -640,6 +646,20 @@ __global__ __launch_bounds__(64 * kWaves, 4) void deferred_kernel(const Deferred
       }
     }
   }
+#ifdef VKR_X_TIMES
+  if ((t & 63u) == 0u) {
+    const uint32_t wave = (blockIdx.y * gridDim.x + blockIdx.x) * kWaves + (t >> 6);
+    if (wave < 65536u) {
+      uint32_t hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      g_wave_times[4u * wave + 0u] = rt_start;
+      g_wave_times[4u * wave + 1u] = wall_clock64();
+      g_wave_times[4u * wave + 2u] = ((unsigned long long)xcc << 32) | hw;
+      g_wave_times[4u * wave + 3u] = __builtin_readcyclecounter() - t_start;
+    }
+  }
+#endif
   if (kIs8Bit) {
     const Where w1 = where(t);
     if (w1.inside) {
@@ -647,6 +667,119 @@ __global__ __launch_bounds__(64 * kWaves, 4) void deferred_kernel(const Deferred
 #pragma unroll
       for (int i = 0; i < 4; ++i) packed[i] = s_stash[kRowAlbedo + i][t];
       store_rgba8x4(p.out + (size_t)w1.y * p.pitch_out, w1.x0, min(4u, p.width - w1.x0), packed);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ whole table, one pixel per lane
+// For launches of a few rounds of workgroups (a screen band of a frame split over several GPUs, a 1080p frame).
+// Three waves of this code fill a SIMD's issue slots and the arbiter serves equal priorities oldest first, so the
+// fourth wave of a SIMD hardly moves until one of the others ends; the SIMD's last wave then runs alone, at half the
+// rate a full SIMD sustains.  While workgroups keep arriving that costs nothing, but at the end of a launch it adds
+// about a ninth of a wave's lifetime (measured, 4K x 256 lights: 36 us per launch with 4 pixels per lane, 19 us with
+// waves half as long, 12 us with a quarter).  So the short launches use the shortest waves: a single-wave workgroup
+// shades 64 consecutive pixels of a row, one per lane, and walks the table once, four lights per trip - the same four
+// (pixel, light) evaluations per trip, and per pixel the same sums in the same order, as the kernels above: the
+// bytes are the same.
+constexpr uint32_t kPixelChunk = 128;  // lights per LDS chunk
+
+template <int kOutMode, bool kRadius>
+__global__ __launch_bounds__(64, 4) void deferred_pixel_kernel(const DeferredParams p) {
+  __shared__ float4 s_light[2 * kPixelChunk + 8];  // + one trip: the prefetch of the last trip reads past the list
+  constexpr bool kIs8Bit = kOutMode == kOutRgba8 || kOutMode == kOutBgra8;
+  const uint32_t t = threadIdx.x;
+  const float4* __restrict__ lights = reinterpret_cast<const float4*>(p.lights);
+  const uint32_t L = p.light_count;
+  LoopConsts kc;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.step_scale) : "s"(kStepScale));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.step_bias) : "s"(-kEarlyOut * kStepScale));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.dist_floor) : "s"(kDistFloor));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.radius2_scaled) : "s"(p.radius2 * kRadiusStepScale));
+
+  const uint32_t x = blockIdx.x * 64u + t, y = blockIdx.y;
+  const bool inside = x < p.width;
+  // lanes beyond the row's end shade the workgroup's first pixel (in bounds by construction) and store nothing
+  const uint32_t lx = inside ? x : blockIdx.x * 64u;
+  const uint32_t alb = *reinterpret_cast<const uint32_t*>(p.albedo + (size_t)y * p.pitch_albedo + (size_t)lx * 4u);
+  const uint32_t mat = *reinterpret_cast<const uint32_t*>(p.material + (size_t)y * p.pitch_material + (size_t)lx * 4u);
+  const float dep = *reinterpret_cast<const float*>(p.depth + (size_t)y * p.pitch_depth + (size_t)lx * 4u);
+  const uint2 nrm = *reinterpret_cast<const uint2*>(p.normal + (size_t)y * p.pitch_normal + (size_t)lx * 8u);
+  Pixel s;
+  {
+    const ExactRcp by_width = exact_rcp((float)p.width), by_height = exact_rcp((float)p.full_height);
+    setup_pixel(s, p, clip_coord(lx, by_width), clip_coord(y + p.row_offset, by_height), dep, mat, nrm.x, nrm.y);
+  }
+  // deferred.comp:43,84: see deferred_kernel - a wave none of whose pixels the loop can change does not walk the table
+  const bool lane_lit = kRadius ? !(s.vn <= kEarlyOut) : (s.vn > kEarlyOut);
+  const bool wave_lit = __ballot(lane_lit) != 0ull;  // wave-uniform
+  const float4 black_pos = make_float4(0.0f, 0.0f, 1e18f, 0.0f), black_col = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  uint32_t probe_left = kProbeBudget;
+  for (uint32_t base = 0; base < L; base += kPixelChunk) {
+    const uint32_t n = min(kPixelChunk, L - base);
+    const uint32_t n4 = (n + 3u) & ~3u;  // padded to whole trips with black lights
+    // one wave: its LDS accesses execute in program order, so only the compiler has to be kept from reordering them
+    for (uint32_t i = t; i < n4; i += 64u) {
+      float4 lp = black_pos, lc = black_col;
+      if (i < n) {
+        lp = lights[3u * (base + i)];       // pos.xyz, opening_angle (unused)
+        lc = lights[3u * (base + i) + 1u];  // color.xyz, penumbra_angle (unused)
+      }
+      s_light[2u * i] = lp;
+      s_light[2u * i + 1u] = lc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (wave_lit) {
+      Probe probe{probe_budget_for(n4 / 4u, probe_left)};
+      const float4* rec = s_light;
+      float4 q0 = rec[0], c0 = rec[1], q1 = rec[2], c1 = rec[3], q2 = rec[4], c2 = rec[5], q3 = rec[6], c3 = rec[7];
+      uint32_t j = 0;
+      for (; j < n4 && probe.budget != 0u; j += 4u) {  // see deferred_kernel: the loop with the test, then the one without
+        const Light four[4] = {{q0.x, q0.y, q0.z, c0.x, c0.y, c0.z}, {q1.x, q1.y, q1.z, c1.x, c1.y, c1.z},
+                               {q2.x, q2.y, q2.z, c2.x, c2.y, c2.z}, {q3.x, q3.y, q3.z, c3.x, c3.y, c3.z}};
+        rec += 8;  // next trip (one trip beyond the list on the last one: read, never used)
+        shade4<kRadius, true>(
+            s, s, four, kc, probe, [&] { q0 = rec[0], q1 = rec[2], q2 = rec[4], q3 = rec[6]; }, [&] { c0 = rec[1], c1 = rec[3], c2 = rec[5], c3 = rec[7]; });
+      }
+      if (j < n4) {
+        // the record index lives in a vector register the compiler cannot see through: one address and eight
+        // immediate offsets per trip, where it would otherwise keep eight scalar addresses and copy each to a
+        // vector register for its read
+        uint32_t at = 2u * j;
+        asm volatile("" : "+v"(at));
+        const float4* rec2 = s_light + at;
+        float4 r0 = rec2[0], d0 = rec2[1], r1 = rec2[2], d1 = rec2[3], r2 = rec2[4], d2 = rec2[5], r3 = rec2[6], d3 = rec2[7];
+        for (; j < n4; j += 4u) {
+          const Light four[4] = {{r0.x, r0.y, r0.z, d0.x, d0.y, d0.z}, {r1.x, r1.y, r1.z, d1.x, d1.y, d1.z},
+                                 {r2.x, r2.y, r2.z, d2.x, d2.y, d2.z}, {r3.x, r3.y, r3.z, d3.x, d3.y, d3.z}};
+          at += 8u;
+          asm volatile("" : "+v"(at));
+          rec2 = s_light + at;
+          r0 = rec2[0], d0 = rec2[1], r1 = rec2[2], d1 = rec2[3], r2 = rec2[4], d2 = rec2[5], r3 = rec2[6], d3 = rec2[7];
+          shade4<kRadius, false>(s, s, four, kc, probe, [] {}, [] {});
+        }
+      }
+      probe_left = probe.budget;
+#ifdef VKR_X_COUNT
+      VKR_COUNT_TRIPS(n4 / 4u, probe.skipped, 0u);
+#endif
+    } else {
+      VKR_COUNT_TRIPS(n4 / 4u, 0u, n4 / 4u);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  float rgb[3];
+  finish_pixel(s, alb, mat, kRadius ? s.in_range > 0.0f : L > 0u, rgb);
+  if (inside) {
+    uint8_t* orow = p.out + (size_t)y * p.pitch_out;
+    if (kIs8Bit) {
+      reinterpret_cast<uint32_t*>(orow)[x] = pack_unorm8<kOutMode>(rgb);
+    } else if (kOutMode == kOutRgba16f) {
+      reinterpret_cast<uint2*>(orow)[x] = half_texel(rgb[0], rgb[1], rgb[2]);
+    } else {
+      reinterpret_cast<float4*>(orow)[x] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
     }
   }
 }
@@ -795,24 +928,22 @@ __global__ __launch_bounds__(64, 4) void deferred_list_kernel(const DeferredPara
       float4 pa = rec[0], ca = rec[1], pb = rec[2], cb = rec[3];
       uint32_t j = 0;
       for (; j < n2 && probe.budget != 0u; j += 2u) {  // see deferred_kernel: the loop with the test, then the one without
-        const Light A{pa.x, pa.y, pa.z, ca.x, ca.y, ca.z};
-        const Light B{pb.x, pb.y, pb.z, cb.x, cb.y, cb.z};
+        const Light AB[2] = {{pa.x, pa.y, pa.z, ca.x, ca.y, ca.z}, {pb.x, pb.y, pb.z, cb.x, cb.y, cb.z}};
         rec += 4;  // next pair (one pair beyond the list on the last trip: read, never used)
         shade4<true, true>(
-            s[0], s[1], A, B, kc, probe, [&] { pa = rec[0], pb = rec[2]; }, [&] { ca = rec[1], cb = rec[3]; });
+            s[0], s[1], AB, kc, probe, [&] { pa = rec[0], pb = rec[2]; }, [&] { ca = rec[1], cb = rec[3]; });
       }
       if (j < n2) {
         const float4* rec2 = s_light + 2u * j;
         float4 pa2 = rec2[0], ca2 = rec2[1], pb2 = rec2[2], cb2 = rec2[3];
         for (; j < n2; j += 2u) {
-          const Light A{pa2.x, pa2.y, pa2.z, ca2.x, ca2.y, ca2.z};
-          const Light B{pb2.x, pb2.y, pb2.z, cb2.x, cb2.y, cb2.z};
+          const Light AB[2] = {{pa2.x, pa2.y, pa2.z, ca2.x, ca2.y, ca2.z}, {pb2.x, pb2.y, pb2.z, cb2.x, cb2.y, cb2.z}};
           rec2 += 4;
           pa2 = rec2[0];
           ca2 = rec2[1];
           pb2 = rec2[2];
           cb2 = rec2[3];
-          shade4<true, false>(s[0], s[1], A, B, kc, probe, [] {}, [] {});
+          shade4<true, false>(s[0], s[1], AB, kc, probe, [] {}, [] {});
         }
       }
       probe_left = probe.budget;
@@ -1189,20 +1320,23 @@ constexpr uint32_t kBinMinLights = 256;
 constexpr uint64_t kBinMaxEntries = 64ull << 20;  // 256 MiB of indices
 constexpr uint32_t kListCap = kChunk;             // entries per tile list: one LDS chunk
 constexpr uint32_t kListMaxLights = 65536;        // list entries are 16-bit light indices
-constexpr uint32_t kFineRounds = 4;               // whole-table launches shorter than this many rounds use single-wave workgroups
+#ifndef VKR_X_FINE_ROUNDS
+#define VKR_X_FINE_ROUNDS 4
+#endif
+constexpr uint32_t kFineRounds = VKR_X_FINE_ROUNDS;               // whole-table launches of fewer rounds of four-wave workgroups than this shade one pixel per lane
 
 template <int kOutMode>
 hipError_t launch_mode(const DeferredParams& p, const TileListOut* lists, uint32_t cu_count, hipStream_t stream) {
   const dim3 grid((p.width + 31u) / 32u, (p.height + 31u) / 32u, 1u);
   const bool radius = (p.flags & 1u) != 0u;
-  // fewer than kFineRounds rounds of four-wave workgroups (four of them fit a CU): single-wave workgroups
+  // fewer than kFineRounds rounds of four-wave workgroups (four of them fit a CU): one pixel per lane, single-wave workgroups
   const bool fine = (p.flags & 4u) == 0u && (uint64_t)grid.x * grid.y < (uint64_t)kFineRounds * 4u * cu_count;
-  const dim3 fine_grid(grid.x, (p.height + 7u) / 8u, 1u);
+  const dim3 fine_grid((p.width + 63u) / 64u, p.height, 1u);  // one wave per 64 pixels of a row
   if (lists == nullptr) {
     if (!radius && !fine) hipLaunchKernelGGL((deferred_kernel<kOutMode, false, 4>), grid, dim3(256), 0, stream, p);
-    if (!radius && fine) hipLaunchKernelGGL((deferred_kernel<kOutMode, false, 1>), fine_grid, dim3(64), 0, stream, p);
+    if (!radius && fine) hipLaunchKernelGGL((deferred_pixel_kernel<kOutMode, false>), fine_grid, dim3(64), 0, stream, p);
     if (radius && !fine) hipLaunchKernelGGL((deferred_kernel<kOutMode, true, 4>), grid, dim3(256), 0, stream, p);
-    if (radius && fine) hipLaunchKernelGGL((deferred_kernel<kOutMode, true, 1>), fine_grid, dim3(64), 0, stream, p);
+    if (radius && fine) hipLaunchKernelGGL((deferred_pixel_kernel<kOutMode, true>), fine_grid, dim3(64), 0, stream, p);
   } else {
     const uint32_t tiles = p.tiles_x * p.tiles_y;
     hipLaunchKernelGGL((tile_lists_kernel<kOutMode>), dim3((tiles + 3u) / 4u), dim3(256), 0, stream, p, *lists);
@@ -1228,6 +1362,11 @@ hipError_t launch_mode(const DeferredParams& p, const TileListOut* lists, uint32
 
 }  // namespace
 
+#ifdef VKR_X_TIMES
+extern "C" __attribute__((visibility("default"))) int vkr_x_wave_times(unsigned long long* out, unsigned waves) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_times), (size_t)waves * 32u) == hipSuccess ? 0 : 1;
+}
+#endif
 #ifdef VKR_X_COUNT
 extern "C" __attribute__((visibility("default"))) int vkr_x_trip_counts(unsigned long long out[3], int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trip_counts), sizeof(g_trip_counts)) != hipSuccess) return 1;
