@@ -118,7 +118,7 @@ def tiled_line(ctx, vkr, synth, frame, K, WU, name, pmc):
     hbm_frac, valu_frac = byt / (ms * 1e-3) / HBM_PEAK, flops / (ms * 1e-3) / VALU_FP32_PEAK
     line = {"value": Wt * Ht / (ms * 1e-3) / 1e9, "unit": "Gpixel/s", "ms_per_call": ms, "lights": Lt, "radius": Rt,
             "workload": f"{Wt}x{Ht}, {Lt} lights, radius cutoff {Rt}, coarse bins + per-tile light lists, {scene}",
-            "L_eff": l_eff, "lists": {k: st[k] for k in ("tiles", "dark_tiles", "listed_tiles", "overflow_tiles", "max_list", "list_cap")},
+            "L_eff": l_eff, "lists": {k: st[k] for k in ("tiles", "dark_tiles", "listed_tiles", "deep_tiles", "overflow_tiles", "max_list", "list_cap")},
             "roofline": {"bound": "hbm" if hbm_frac >= valu_frac else "valu_fp32", "frac": max(hbm_frac, valu_frac), "hbm_frac": hbm_frac,
                          "valu_frac": valu_frac, "algorithmic_bytes": byt, "algorithmic_flops": flops, "traffic": None, "dram_frac": None},
             "hbm_frac": hbm_frac, "algorithmic_bytes": byt}

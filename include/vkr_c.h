@@ -161,8 +161,11 @@ typedef struct vkr_tile_stats {
   uint32_t overflow_tiles; /* more reaching lights than a list holds: shaded from their bin's candidates / the table */
   uint32_t max_list;       /* longest list among the listed tiles */
   uint32_t list_cap;       /* entries a list holds */
-  uint64_t light_pixels;   /* sum over tiles of lights walked x pixels of the tile inside the image */
+  uint64_t light_pixels;   /* sum over tiles (for deep tiles: over their groups of pixels) of lights walked x pixels inside the image */
   uint64_t pixels;         /* width x height */
+  uint32_t deep_tiles;     /* listed tiles that span more depth than a light reaches: shaded in groups of 128 pixels of
+                              similar depth, each group walking the part of the tile's list that can reach it */
+  uint32_t reserved;
 } vkr_tile_stats;
 VKR_API int32_t vkr_deferred_tile_stats(vkr_context* ctx, vkr_tile_stats* out);
 

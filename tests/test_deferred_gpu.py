@@ -228,6 +228,50 @@ def test_radius_cutoff_with_coarse_bins(vkr, synth, ctx, w, h, lights, radius):
                 assert np.array_equal(a.view(np.uint16), got.astype(np.float16).view(np.uint16))
 
 
+def test_depth_grouped_tiles(vkr, synth):
+    """A tile whose pixels span more depth than the radius has them sorted into eight depth groups, each with a
+    list of its own.  Frames of such tiles (depth uncorrelated between neighbours) in every output format, a band
+    of rows, a light cluster that overflows one group's list (that group falls back on the tile's list), and the
+    decision the library takes from the frame before (a frame without deep tiles, then frames with them, then
+    without again): always the bytes of the whole-table loop."""
+    ctx = vkr.Context(0)
+    tiled, flat_flags = vkr.DEFERRED_RADIUS_CUTOFF, vkr.DEFERRED_RADIUS_CUTOFF | vkr.DEFERRED_NO_TILE_LISTS
+    w, h = 416, 200  # 13 x 7 tiles, the last row and column partial
+    noisy = synth.deferred_case(w, h, 3000, config_index=9)
+    noisy["push"] = noisy["push"].copy()
+    noisy["push"][3] = 25.0
+    smooth = dict(noisy, gbuf=dict(noisy["gbuf"], depth=np.full((h, w), 0.995, np.float32)))
+    flat = {}
+    for name, case in (("noisy", noisy), ("smooth", smooth)):
+        flat[name], _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT, flags=flat_flags)
+    deep_seen = []
+    for name in ("smooth", "noisy", "noisy", "noisy", "smooth", "smooth", "noisy"):
+        got, _ = run_deferred_gpu(vkr, ctx, {"noisy": noisy, "smooth": smooth}[name], vkr.FORMAT_R32G32B32A32_SFLOAT, flags=tiled)
+        assert np.array_equal(got, flat[name]), name
+        deep_seen.append(ctx.tile_stats()["deep_tiles"])
+    assert deep_seen[0] == 0 and deep_seen[4] == 0 and deep_seen[5] == 0
+    assert deep_seen[2] > 20 and deep_seen[3] == deep_seen[2]  # by its second frame at the latest the noisy scene is shaded in depth groups
+    for fmt in (vkr.FORMAT_R16G16B16A16_SFLOAT, vkr.FORMAT_R8G8B8A8_UNORM, vkr.FORMAT_B8G8R8A8_UNORM):
+        a, _ = run_deferred_gpu(vkr, ctx, noisy, fmt, flags=tiled)
+        a, _ = run_deferred_gpu(vkr, ctx, noisy, fmt, flags=tiled)
+        assert ctx.tile_stats()["deep_tiles"] > 20
+        b, _ = run_deferred_gpu(vkr, ctx, noisy, fmt, flags=flat_flags)
+        assert np.array_equal(a, b), fmt
+    band, _ = run_deferred_gpu(vkr, ctx, noisy, vkr.FORMAT_R32G32B32A32_SFLOAT, flags=tiled, rows=(37, 150))
+    assert np.array_equal(band[37:150], flat["noisy"][37:150]) and not band[:37].any() and not band[150:].any()
+    # 200 lights within a unit of one pixel's position: its depth group lists more than a group's list holds
+    crowd = dict(noisy, lights=noisy["lights"][:500].copy())
+    pos = synth.unproject(noisy["camera"]["inv_vp"], w, h, noisy["gbuf"]["depth"])[100, 210]
+    rng = np.random.default_rng(5)
+    crowd["lights"][:200, 0:3] = (pos + rng.uniform(-1, 1, (200, 3))).astype(np.float32)
+    want, _ = run_deferred_gpu(vkr, ctx, crowd, vkr.FORMAT_R32G32B32A32_SFLOAT, flags=flat_flags)
+    for _ in range(2):
+        got, _ = run_deferred_gpu(vkr, ctx, crowd, vkr.FORMAT_R32G32B32A32_SFLOAT, flags=tiled)
+        assert np.array_equal(got, want)
+    st = ctx.tile_stats()
+    assert st["deep_tiles"] > 0 and st["max_list"] >= 200 and st["overflow_tiles"] == 0
+
+
 def test_radius_argument_range(vkr, synth, ctx):
     case = synth.deferred_case(16, 4, 1)
     gb = vkr.GBuffer(ctx, 16, 4).upload(case["gbuf"])

@@ -345,7 +345,7 @@ def test_resolve_kernels_use_no_scratch_memory():
         assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0, (name, k)
         assert k["vgpr_count"] <= 128, (name, k)  # four waves per SIMD
         checked += 1
-    assert checked == 8 + 4 + 4 + 1  # four output formats each of: whole-table kernel (four pixels per lane, and one), list shading, list building; the bins
+    assert checked == 8 + 8 + 4 + 1  # four output formats each of: whole-table kernel (four pixels per lane, and one), list shading (strips, and deep tiles), list building; the bins
 
 
 @pytest.mark.parametrize("unit", ["cull", "scene", "gbuffer"])

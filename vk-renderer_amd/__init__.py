@@ -60,7 +60,8 @@ class DeferredArgs(C.Structure):
 
 class TileStats(C.Structure):
     _fields_ = [("tiles", C.c_uint32), ("dark_tiles", C.c_uint32), ("listed_tiles", C.c_uint32), ("overflow_tiles", C.c_uint32),
-                ("max_list", C.c_uint32), ("list_cap", C.c_uint32), ("light_pixels", C.c_uint64), ("pixels", C.c_uint64)]
+                ("max_list", C.c_uint32), ("list_cap", C.c_uint32), ("light_pixels", C.c_uint64), ("pixels", C.c_uint64),
+                ("deep_tiles", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class CullArgs(C.Structure):

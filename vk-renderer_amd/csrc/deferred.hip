@@ -784,211 +784,31 @@ __global__ __launch_bounds__(64, 4) void deferred_pixel_kernel(const DeferredPar
   }
 }
 
-// ------------------------------------------------------------------ shading from tile light lists (radius cutoff)
-// One wave per workgroup; the unit of work is a 32 x 4 pixel strip of a lit tile: lane l owns the two pixels
-// (2*(l&15), 2*(l&15)+1) of row l>>4 of the strip, shaded as one pair, two lights per loop trip (the same four
-// evaluations per trip as the whole-table kernel).  A lit tile is 8 units.  What bounds this launch on sparse
-// frames is not arithmetic but the chain of dependent memory round trips in front of every unit (queue entry ->
-// list length -> light indices -> light records), a few microseconds each time: with 256-thread workgroups
-// taking whole or half tiles, a CU had 3-4 such chains in flight and the launch took (units per workgroup) x
-// (chain), 34 us for 690 lit tiles of at most 6 lights.  Single-wave workgroups put 16 chains in flight per CU,
-// need no barriers, and their list chunk of 64 lights is one record per lane.
-// Units are dealt out statically: wave w of the grid takes units w, w + G, ... of the lit tiles in queue order,
-// heaviest list class first (the eight strips of a tile land on neighbouring waves, so its list and its plane
-// rows are fetched together).  The queue lengths are fixed before the launch, so every wave's loop ends.
-// A tile whose list overflowed its capacity walks its coarse bin's candidates (or the whole table) instead; the
-// per-pixel cutoff makes any superset of the reaching lights give the same bits.
-// Measured and dropped: asking for the list's length, the lane's first list entry (before the length is known) and
-// the planes together, so that the light records are requested one round trip earlier - 37.8 / 86.0 / 172.8 us
-// against 38.3 / 86.2 / 170.1 us (4K x 256, 4K x 4096, 8K x 4096): with 16 waves per CU in different phases the
-// chain's length is not what the launch waits for any more.
-constexpr uint32_t kStripRows = 4, kStripsPerTile = 32 / kStripRows, kWaveChunk = 64;
-
-template <int kOutMode>
-__global__ __launch_bounds__(64, 4) void deferred_list_kernel(const DeferredParams p) {
-  __shared__ float4 s_light[2 * kWaveChunk + 4];  // +1 pair: the prefetch of the last iteration reads past the list
-  __shared__ uint32_t s_keep[4][64];
-  constexpr bool kIs8Bit = kOutMode == kOutRgba8 || kOutMode == kOutBgra8;
-  const uint32_t t = threadIdx.x;
-  const float4* __restrict__ lights = reinterpret_cast<const float4*>(p.lights);
-  const uint32_t L = p.light_count;
-  LoopConsts kc;
-  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.step_scale) : "s"(kStepScale));
-  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.step_bias) : "s"(-kEarlyOut * kStepScale));
-  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.dist_floor) : "s"(kDistFloor));
-  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.radius2_scaled) : "s"(p.radius2 * kRadiusStepScale));
-
-  uint32_t class_end[kListClasses];
-  {
-    uint32_t run = 0;
-#pragma unroll
-    for (int c = kListClasses - 1; c >= 0; --c) {
-      run += p.lit_counters[c];
-      class_end[kListClasses - 1 - c] = run;
-    }
-  }
-  const uint32_t q_end = kStripsPerTile * class_end[kListClasses - 1];
-#pragma unroll 1
-  for (uint32_t q = blockIdx.x; q < q_end; q += gridDim.x) {
-    const uint32_t pos = q / kStripsPerTile, strip = q % kStripsPerTile;
-    uint32_t cls = kListClasses - 1u, first = 0u;  // position of the concatenated queues -> (class, index)
-#pragma unroll
-    for (uint32_t k = 0; k + 1u < kListClasses; ++k)
-      if (pos >= class_end[k]) cls = kListClasses - 2u - k, first = class_end[k];
-    const uint32_t tile = p.lit_queue[(size_t)cls * (p.tiles_x * p.tiles_y) + (pos - first)];
-    const uint32_t tile_y = tile / p.tiles_x, tile_x = tile - tile_y * p.tiles_x;
-    uint32_t count = L;                           // lights this unit walks
-    const uint16_t* __restrict__ tl = nullptr;    // the tile's own list, or
-    const uint32_t* __restrict__ cand = nullptr;  // its bin's candidates when the list overflowed
-    {
-      const uint32_t word = p.tile_count[tile];
-      if (word & kTileOverflow) {
-        if (p.bin_list) {
-          const uint32_t bin_index = (tile_y * 32u / kBinPixels) * p.bins_x + tile_x * 32u / kBinPixels;
-          cand = p.bin_list + (size_t)bin_index * L;
-          count = p.bin_count[bin_index];
-        }
-      } else {
-        tl = p.tile_list + (size_t)tile * p.list_cap;
-        count = word;
-      }
-    }
-    // Where the lane's two pixels are: derived from the thread index where needed (through a copy the compiler
-    // cannot see through) rather than kept across the light loop, which leaves no register for values that wait.
-    struct Where {
-      uint32_t x0, y, lx, ly;
-      bool inside;
-    };
-    auto where = [&](uint32_t tq) {
-      uint32_t ox = tile_x * 32u, oy = tile_y * 32u, oys = tile_y * 32u + strip * kStripRows;
-      asm volatile("" : "+v"(tq), "+s"(ox), "+s"(oy), "+s"(oys));
-      Where w;
-      w.x0 = ox + (tq & 15u) * 2u;
-      w.y = oys + (tq >> 4);
-      w.inside = (w.x0 < p.width) && (w.y < p.height);
-      // lanes outside the image shade the tile's first pair (in bounds by construction) and store nothing
-      w.lx = w.inside ? w.x0 : ox;
-      w.ly = w.inside ? w.y : oy;
-      return w;
-    };
-    const Where w0 = where(t);
-    if (__ballot(w0.inside) == 0ull) continue;  // a strip below the image's last row (wave-uniform)
-    const uint32_t lx = w0.lx, ly = w0.ly;
-    const uint2 alb2 = *reinterpret_cast<const uint2*>(p.albedo + (size_t)ly * p.pitch_albedo + (size_t)lx * 4u);
-    const uint2 mat2 = *reinterpret_cast<const uint2*>(p.material + (size_t)ly * p.pitch_material + (size_t)lx * 4u);
-    const float2 dep2 = *reinterpret_cast<const float2*>(p.depth + (size_t)ly * p.pitch_depth + (size_t)lx * 4u);
-    const uint4 nrm = *reinterpret_cast<const uint4*>(p.normal + (size_t)ly * p.pitch_normal + (size_t)lx * 8u);
-    // the first chunk of the list is requested alongside the planes: one index, then one record, per lane
-    const float4 black_pos = make_float4(0.0f, 0.0f, 1e18f, 0.0f), black_col = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    auto fetch_chunk = [&](uint32_t base, float4& lp, float4& lc) {
-      lp = black_pos;
-      lc = black_col;
-      if (base + t < count) {
-        const uint32_t j = base + t;
-        const uint32_t idx = tl ? (uint32_t)tl[j] : (cand ? cand[j] : j);
-        lp = lights[3u * idx];       // pos.xyz, opening_angle (unused)
-        lc = lights[3u * idx + 1u];  // color.xyz, penumbra_angle (unused)
-      }
-    };
-    float4 lp, lc;
-    fetch_chunk(0u, lp, lc);
-    uint32_t width = p.width, full_height = p.full_height;
-    asm volatile("" : "+s"(width), "+s"(full_height));  // their reciprocals are derived per unit, not kept in vector registers
-    const ExactRcp by_width = exact_rcp((float)width), by_height = exact_rcp((float)full_height);
-    const float cy = clip_coord(ly + p.row_offset, by_height);
-    Pixel s[2];
-    setup_pixel(s[0], p, clip_coord(lx, by_width), cy, dep2.x, mat2.x, nrm.x, nrm.y);
-    setup_pixel(s[1], p, clip_coord(lx + 1u, by_width), cy, dep2.y, mat2.y, nrm.z, nrm.w);
-    // the albedo and material words are decoded after the loop: they wait in LDS, one column per lane
-    s_keep[0][t] = alb2.x;
-    s_keep[1][t] = alb2.y;
-    s_keep[2][t] = mat2.x;
-    s_keep[3][t] = mat2.y;
-
-    uint32_t probe_left = kProbeBudget;
-    // a wave whose pixels all have a v.n that is a number <= 1e-6 gets 0 from every light (deferred.comp:43,84) and
-    // does not need to know whether one lay in range: it keeps its ambient colour either way
-    if (__ballot(!(s[0].vn <= kEarlyOut) || !(s[1].vn <= kEarlyOut)) == 0ull) {
-      VKR_COUNT_TRIPS((count + 1u) / 2u, 0u, (count + 1u) / 2u);
-      count = 0u;
-    }
-    for (uint32_t base = 0; base < count; base += kWaveChunk) {
-      const uint32_t n = min(kWaveChunk, count - base);
-      const uint32_t n2 = (n + 1u) & ~1u;
-      // one wave: its LDS accesses execute in program order, no barrier is needed between the loop's reads of
-      // the previous chunk and these writes
-      s_light[2u * t] = lp;
-      s_light[2u * t + 1u] = lc;
-      Probe probe{probe_budget_for(n2 / 2u, probe_left)};
-      if (base + kWaveChunk < count) fetch_chunk(base + kWaveChunk, lp, lc);  // the next chunk, while this one is shaded
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const float4* rec = s_light;
-      float4 pa = rec[0], ca = rec[1], pb = rec[2], cb = rec[3];
-      uint32_t j = 0;
-      for (; j < n2 && probe.budget != 0u; j += 2u) {  // see deferred_kernel: the loop with the test, then the one without
-        const Light AB[2] = {{pa.x, pa.y, pa.z, ca.x, ca.y, ca.z}, {pb.x, pb.y, pb.z, cb.x, cb.y, cb.z}};
-        rec += 4;  // next pair (one pair beyond the list on the last trip: read, never used)
-        shade4<true, true>(
-            s[0], s[1], AB, kc, probe, [&] { pa = rec[0], pb = rec[2]; }, [&] { ca = rec[1], cb = rec[3]; });
-      }
-      if (j < n2) {
-        const float4* rec2 = s_light + 2u * j;
-        float4 pa2 = rec2[0], ca2 = rec2[1], pb2 = rec2[2], cb2 = rec2[3];
-        for (; j < n2; j += 2u) {
-          const Light AB[2] = {{pa2.x, pa2.y, pa2.z, ca2.x, ca2.y, ca2.z}, {pb2.x, pb2.y, pb2.z, cb2.x, cb2.y, cb2.z}};
-          rec2 += 4;
-          pa2 = rec2[0];
-          ca2 = rec2[1];
-          pb2 = rec2[2];
-          cb2 = rec2[3];
-          shade4<true, false>(s[0], s[1], AB, kc, probe, [] {}, [] {});
-        }
-      }
-      probe_left = probe.budget;
-#ifdef VKR_X_COUNT
-      VKR_COUNT_TRIPS(n2 / 2u, probe.skipped, 0u);
-#endif
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-    float rgb[2][3];
-    finish_pixel(s[0], s_keep[0][t], s_keep[2][t], s[0].in_range > 0.0f, rgb[0]);
-    finish_pixel(s[1], s_keep[1][t], s_keep[3][t], s[1].in_range > 0.0f, rgb[1]);
-    const Where w1 = where(t);
-    if (w1.inside) {
-      const uint32_t x0 = w1.x0, y = w1.y;
-      const bool both = x0 + 1u < p.width;
-      uint8_t* orow = p.out + (size_t)y * p.pitch_out;
-      if (kIs8Bit) {
-        uint32_t* o = reinterpret_cast<uint32_t*>(orow) + x0;
-        const uint32_t w0 = pack_unorm8<kOutMode>(rgb[0]), w1 = pack_unorm8<kOutMode>(rgb[1]);
-        if (both)
-          *reinterpret_cast<uint2*>(o) = make_uint2(w0, w1);
-        else
-          o[0] = w0;
-      } else if (kOutMode == kOutRgba16f) {
-        uint2* o = reinterpret_cast<uint2*>(orow) + x0;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          if (i == 0 || both) o[i] = half_texel(rgb[i][0], rgb[i][1], rgb[i][2]);
-        }
-      } else {
-        float4* o = reinterpret_cast<float4*>(orow) + x0;
-        o[0] = make_float4(rgb[0][0], rgb[0][1], rgb[0][2], 1.0f);
-        if (both) o[1] = make_float4(rgb[1][0], rgb[1][1], rgb[1][2], 1.0f);
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------ tile light lists (radius cutoff)
+// ------------------------------------------------------------------ bounds of a tile's pixel positions
 // Wave-uniform bounds of a tile's pixel positions: a padded world-space box and the four side faces of the
 // tile's view pyramid (outward unit normal + offset), plus reach = radius + pad.
 struct TileBounds {
   float lo[3], hi[3], face[4][4], reach;
+  float span;  // distance between the near and the far point of the box's first corner ray
 };
+
+// How far a pixel position as the resolve reconstructs it (deferred.comp:99-103 in binary32) can lie from the exact
+// image of its clip-space point.  w = M3 cx + M7 cy + M11 d + M15 cancels as depth -> 1 (with the reference's
+// near 0.1 / far 10000 the two last terms are about +-5 while their sum is 5e-4 at 1800 units), so each coordinate
+// x / w carries a relative error of eps * (sum of |terms of w|) / |w| plus that of its own numerator; `terms_w` and
+// `terms_xyz` bound the sums of absolute terms.  kPositionEps allows for every rounding of the evaluation (four
+// products, three sums, the correctly rounded divisions) and doubles the result.
+constexpr float kPositionEps = 0x1p-20f;  // 16 * 2^-24
+__device__ __forceinline__ float position_error_bound(float max_abs_coord, float terms_w, float terms_xyz, float min_abs_w) {
+  return kPositionEps * fma_(max_abs_coord, terms_w, terms_xyz) / min_abs_w + kPositionEps * max_abs_coord;
+}
+
+// Bit patterns that order like the numbers they stand for (not-a-number aside), for integer min / max.
+__device__ __forceinline__ uint32_t ordered_bits(float v) {
+  const uint32_t b = __float_as_uint(v);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float from_ordered_bits(uint32_t o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o); }
 
 __device__ __forceinline__ float lane_value(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 
@@ -1029,8 +849,21 @@ __device__ __forceinline__ TileBounds tile_bounds(const DeferredParams& p, uint3
     }
     scale = fmaxf(scale, fmaxf(fabsf(box_lo[a]), fabsf(box_hi[a])));
   }
-  // binary32 reconstruction error of a position is ~2e-4 relative at the far end of the depth range
-  const float pad = 2e-3f * scale + 1e-2f;
+  // The pad covers the error of the reconstructed pixel positions.  Every term of the bound is largest at a corner
+  // of the clip-space box (|linear form| and 1 / |w| of a linear w that keeps its sign are), so the maxima over the
+  // eight corners bound it for every pixel of the tile.
+  float terms_w = fabsf(M[3] * pcx) + fabsf(M[7] * pcy) + fabsf(M[11] * pcz) + fabsf(M[15]);
+  float terms_xyz = fmaxf(fmaxf(fabsf(M[0] * pcx) + fabsf(M[4] * pcy) + fabsf(M[8] * pcz) + fabsf(M[12]),
+                                fabsf(M[1] * pcx) + fabsf(M[5] * pcy) + fabsf(M[9] * pcz) + fabsf(M[13])),
+                          fabsf(M[2] * pcx) + fabsf(M[6] * pcy) + fabsf(M[10] * pcz) + fabsf(M[14]));
+  float min_w = fabsf(ww);
+#pragma unroll
+  for (int off = 1; off <= 4; off <<= 1) {
+    terms_w = fmaxf(terms_w, __shfl_xor(terms_w, off));
+    terms_xyz = fmaxf(terms_xyz, __shfl_xor(terms_xyz, off));
+    min_w = fminf(min_w, __shfl_xor(min_w, off));
+  }
+  const float pad = position_error_bound(scale, terms_w, terms_xyz, min_w) + 1e-3f;
   // the four side faces of the tile's pyramid, face c in lane c: plane through rays c and c+1, normal pointing
   // away from ray c+2
   float near1[3], near2[3], ray[3];
@@ -1065,9 +898,347 @@ __device__ __forceinline__ TileBounds tile_bounds(const DeferredParams& p, uint3
     b.face[f][3] = lane_value(fw, f);
   }
   b.reach = sqrt_(p.radius2) + lane_value(pad, 0);
+  const float sx = lane_value(q[0], 4) - lane_value(q[0], 0), sy = lane_value(q[1], 4) - lane_value(q[1], 0), sz = lane_value(q[2], 4) - lane_value(q[2], 0);
+  b.span = sane ? sqrt_(fma_(sz, sz, fma_(sy, sy, sx * sx))) : 0.0f;
   return b;
 }
 
+// ------------------------------------------------------------------ shading from tile light lists (radius cutoff)
+// One wave per workgroup; the unit of work is a 32 x 4 pixel strip of a lit tile: lane l owns the two pixels
+// (2*(l&15), 2*(l&15)+1) of row l>>4 of the strip, shaded as one pair, two lights per loop trip (the same four
+// evaluations per trip as the whole-table kernel).  A lit tile is 8 units.  What bounds this launch on sparse
+// frames is not arithmetic but the chain of dependent memory round trips in front of every unit (queue entry ->
+// list length -> light indices -> light records), a few microseconds each time: with 256-thread workgroups
+// taking whole or half tiles, a CU had 3-4 such chains in flight and the launch took (units per workgroup) x
+// (chain), 34 us for 690 lit tiles of at most 6 lights.  Single-wave workgroups put 16 chains in flight per CU,
+// need no barriers, and their list chunk of 64 lights is one record per lane.
+// Units are dealt out statically: wave w of the grid takes units w, w + G, ... of the lit tiles in queue order,
+// heaviest list class first (the eight strips of a tile land on neighbouring waves, so its list and its plane
+// rows are fetched together).  The queue lengths are fixed before the launch, so every wave's loop ends.
+// A tile whose list overflowed its capacity walks its coarse bin's candidates (or the whole table) instead; the
+// per-pixel cutoff makes any superset of the reaching lights give the same bits.
+// Measured and dropped: asking for the list's length, the lane's first list entry (before the length is known) and
+// the planes together, so that the light records are requested one round trip earlier - 37.8 / 86.0 / 172.8 us
+// against 38.3 / 86.2 / 170.1 us (4K x 256, 4K x 4096, 8K x 4096): with 16 waves per CU in different phases the
+// chain's length is not what the launch waits for any more.
+constexpr uint32_t kStripRows = 4, kStripsPerTile = 32 / kStripRows, kWaveChunk = 64;
+#ifndef VKR_X_DEEP_MIN
+#define VKR_X_DEEP_MIN 8
+#endif
+constexpr uint32_t kDeepMinList = VKR_X_DEEP_MIN;  // shorter lists are walked whole: narrowing them costs more than it saves
+constexpr float kDeepSpanRadii = 1.0f;    // a tile is deep when its near and far ends are further apart than this many radii
+
+// kDeep = false: single-wave workgroups over the strips of the tiles in the four list-class queues, as described above.
+// kDeep = true : the tiles that tile_lists_kernel marked deep (more depth than a light reaches).  A workgroup of
+// four waves takes one such tile: the tile's four planes go through LDS (read from memory once, in whole rows), wave w
+// shades groups w and w + 4 of the tile's depth order - 128 pixels of similar depth each, wherever they lie in the
+// tile - from the groups' own lists, and the 8-bit result leaves through LDS again, in whole rows.  (With the groups' pixels fetched
+// straight from memory, every wave touched nearly every cache line of the tile: eight times the traffic, in 4-byte
+// pieces - 1.2 ms for the 8K frame whose depth is uncorrelated between neighbours.)
+template <int kOutMode, bool kDeep>
+__global__ __launch_bounds__(kDeep ? 256 : 64, 4) void deferred_list_kernel(const DeferredParams p) {
+  constexpr uint32_t kWaves = kDeep ? 4u : 1u, kTilePixels = kDeep ? 1024u : 1u;
+  __shared__ float4 s_light_of[kWaves][2 * kWaveChunk + 4];  // +1 pair: the prefetch of the last iteration reads past the list
+  __shared__ uint32_t s_keep_of[kDeep ? 1 : 4][64];           // strips: albedo and material words, waiting for the end of the loop
+  __shared__ uint32_t s_alb[kTilePixels], s_mat[kTilePixels], s_out[kTilePixels];  // deep: the tile's planes, texel y * 32 + x
+  __shared__ float s_dep[kTilePixels];
+  __shared__ uint2 s_nrm[kTilePixels];
+  constexpr bool kIs8Bit = kOutMode == kOutRgba8 || kOutMode == kOutBgra8;
+  const uint32_t t = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // lane, wave of the workgroup (the same in every lane)
+  float4* const s_light = s_light_of[wv];
+  const float4* __restrict__ lights = reinterpret_cast<const float4*>(p.lights);
+  const uint32_t L = p.light_count;
+  LoopConsts kc;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.step_scale) : "s"(kStepScale));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.step_bias) : "s"(-kEarlyOut * kStepScale));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.dist_floor) : "s"(kDistFloor));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.radius2_scaled) : "s"(p.radius2 * kRadiusStepScale));
+
+  uint32_t class_end[kListClasses];
+  {
+    uint32_t run = 0;
+#pragma unroll
+    for (int c = kListClasses - 1; c >= 0; --c) {
+      run += p.lit_counters[c];
+      class_end[kListClasses - 1 - c] = run;
+    }
+  }
+  const uint32_t n_tiles = p.tiles_x * p.tiles_y;
+  const uint32_t q_end = kDeep ? p.lit_counters[kListClasses] : kStripsPerTile * class_end[kListClasses - 1];
+  // for the host's next call: how many tiles of this frame qualify as deep (a store to host memory, nobody waits for it)
+  if (!kDeep && blockIdx.x == 0u && threadIdx.x == 0u && p.deep_hint) __hip_atomic_store(p.deep_hint, p.lit_counters[kDeepCounter], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll 1
+  for (uint32_t q = blockIdx.x; q < q_end; q += gridDim.x) {
+    uint32_t tile, strip;
+    if (kDeep) {
+      tile = p.lit_queue[(size_t)kListClasses * n_tiles + q];
+      strip = wv;  // the first of the two groups of the tile's depth order this wave shades
+    } else {
+      const uint32_t pos = q / kStripsPerTile;
+      strip = q % kStripsPerTile;
+      uint32_t cls = kListClasses - 1u, first = 0u;  // position of the concatenated queues -> (class, index)
+#pragma unroll
+      for (uint32_t k = 0; k + 1u < kListClasses; ++k)
+        if (pos >= class_end[k]) cls = kListClasses - 2u - k, first = class_end[k];
+      tile = p.lit_queue[(size_t)cls * n_tiles + (pos - first)];
+    }
+    const uint32_t tile_y = tile / p.tiles_x, tile_x = tile - tile_y * p.tiles_x;
+    const uint32_t word = p.tile_count[tile];
+    if (kDeep) {
+      // the tile's planes, 16 bytes per thread and request (rows hold whole 4-texel groups): 256 requests each for albedo,
+      // material and depth, 512 for the normals
+      {
+        uint32_t c = threadIdx.x;
+        asm volatile("" : "+v"(c));  // addresses derived per tile, not kept from the kernel's entry across the light loop
+        const uint32_t r = c >> 3, x4 = (c & 7u) * 4u;
+        const uint32_t gx = tile_x * 32u + x4, gy = tile_y * 32u + r;
+        if (gx < p.width && gy < p.height) {
+          *reinterpret_cast<uint4*>(s_alb + r * 32u + x4) = *reinterpret_cast<const uint4*>(p.albedo + (size_t)gy * p.pitch_albedo + (size_t)gx * 4u);
+          *reinterpret_cast<uint4*>(s_mat + r * 32u + x4) = *reinterpret_cast<const uint4*>(p.material + (size_t)gy * p.pitch_material + (size_t)gx * 4u);
+          *reinterpret_cast<float4*>(s_dep + r * 32u + x4) = *reinterpret_cast<const float4*>(p.depth + (size_t)gy * p.pitch_depth + (size_t)gx * 4u);
+        }
+#pragma unroll
+        for (uint32_t h = 0; h < 2u; ++h) {  // two 8-byte texels per request
+          const uint32_t c2 = c + 256u * h, r2 = c2 >> 4, x2 = (c2 & 15u) * 2u;
+          const uint32_t hx = tile_x * 32u + x2, hy = tile_y * 32u + r2;
+          if (hx < p.width && hy < p.height)
+            *reinterpret_cast<uint4*>(s_nrm + r2 * 32u + x2) = *reinterpret_cast<const uint4*>(p.normal + (size_t)hy * p.pitch_normal + (size_t)hx * 8u);
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll 1
+    for (uint32_t pass = 0; pass < (kDeep ? 2u : 1u); ++pass) {  // a deep tile's wave shades two groups, one after the other
+    if (kDeep) strip = wv + 4u * pass;
+    uint32_t count = L;                           // lights this unit walks
+    const uint16_t* __restrict__ tl = nullptr;    // the tile's (or the group's) own list, or
+    const uint32_t* __restrict__ cand = nullptr;  // its bin's candidates when the list overflowed
+    if (word & kTileOverflow) {
+      if (p.bin_list) {
+        const uint32_t bin_index = (tile_y * 32u / kBinPixels) * p.bins_x + tile_x * 32u / kBinPixels;
+        cand = p.bin_list + (size_t)bin_index * L;
+        count = p.bin_count[bin_index];
+      }
+    } else {
+      tl = p.tile_list + (size_t)tile * p.list_cap;
+      count = word & kTileCountMask;
+    }
+    bool active = true;  // wave-uniform; only a deep tile's workgroup keeps waves without work (they meet the barriers)
+    if (kDeep) {
+      const uint32_t tile_pixels = min(32u, p.width - tile_x * 32u) * min(32u, p.height - tile_y * 32u);
+      active = strip * 128u < tile_pixels;  // a tile at the image's edge has fewer groups
+      // the group's own list: the part of the tile's list that can reach the group's depth range (tile_lists_kernel)
+      const uint32_t own = active ? p.group_count[(size_t)tile * kStripsPerTile + strip] : 0u;
+      if (own != kGroupOverflow) {
+        tl = p.group_list + ((size_t)tile * kStripsPerTile + strip) * kGroupListCap;
+        count = own;
+      }
+    }
+    // Where the lane's two pixels a and b are: derived from the thread index where needed (through a copy the compiler
+    // cannot see through) rather than kept across the light loop, which leaves no register for values that wait.
+    // A strip's lane has two neighbouring pixels of a row; a deep tile's lane has entries 2l and 2l+1 of its group in
+    // the tile's depth order (ida, idb: y * 32 + x within the tile).  A pixel that does not exist (beyond the image,
+    // or beyond the tile's last pixel) is replaced by one that does and not stored.
+    struct Where {
+      uint32_t xa, ya, xb, yb, ida, idb;
+      bool ina, inb;
+    };
+    auto where = [&](uint32_t tq) {
+      uint32_t ox = tile_x * 32u, oy = tile_y * 32u, oys = tile_y * 32u + strip * kStripRows;
+      asm volatile("" : "+v"(tq), "+s"(ox), "+s"(oy), "+s"(oys));
+      Where w;
+      if (!kDeep) {
+        const uint32_t x0 = ox + (tq & 15u) * 2u, y = oys + (tq >> 4);
+        const bool inside = (x0 < p.width) && (y < p.height);
+        w.xa = inside ? x0 : ox;
+        w.ya = w.yb = inside ? y : oy;
+        w.xb = w.xa + 1u;  // may lie in the row's padding: read, never stored
+        w.ina = inside;
+        w.inb = inside && x0 + 1u < p.width;
+        w.ida = w.idb = 0u;
+      } else {
+        const uint32_t tile_pixels = min(32u, p.width - ox) * min(32u, p.height - oy);
+        const uint32_t j = strip * 128u + 2u * tq;
+        w.ina = j < tile_pixels;
+        w.inb = j + 1u < tile_pixels;
+        const uint32_t pair = reinterpret_cast<const uint32_t*>(p.tile_order + (size_t)tile * 1024u)[(w.ina ? j : strip * 128u) >> 1];
+        w.ida = pair & 0xFFFFu;
+        w.idb = w.inb ? pair >> 16 : w.ida;
+        w.xa = ox + (w.ida & 31u);
+        w.ya = oy + (w.ida >> 5);
+        w.xb = ox + (w.idb & 31u);
+        w.yb = oy + (w.idb >> 5);
+      }
+      return w;
+    };
+    if (active) {
+      const Where w0 = where(t);
+      if (!kDeep && __ballot(w0.ina) == 0ull) continue;  // a strip below the image's last row (wave-uniform)
+      uint2 alb2, mat2;
+      float2 dep2;
+      uint4 nrm;
+      if (!kDeep) {
+        alb2 = *reinterpret_cast<const uint2*>(p.albedo + (size_t)w0.ya * p.pitch_albedo + (size_t)w0.xa * 4u);
+        mat2 = *reinterpret_cast<const uint2*>(p.material + (size_t)w0.ya * p.pitch_material + (size_t)w0.xa * 4u);
+        dep2 = *reinterpret_cast<const float2*>(p.depth + (size_t)w0.ya * p.pitch_depth + (size_t)w0.xa * 4u);
+        nrm = *reinterpret_cast<const uint4*>(p.normal + (size_t)w0.ya * p.pitch_normal + (size_t)w0.xa * 8u);
+      } else {
+        alb2 = make_uint2(s_alb[w0.ida], s_alb[w0.idb]);
+        mat2 = make_uint2(s_mat[w0.ida], s_mat[w0.idb]);
+        dep2 = make_float2(s_dep[w0.ida], s_dep[w0.idb]);
+        const uint2 na = s_nrm[w0.ida], nb = s_nrm[w0.idb];
+        nrm = make_uint4(na.x, na.y, nb.x, nb.y);
+      }
+      const float4 black_pos = make_float4(0.0f, 0.0f, 1e18f, 0.0f), black_col = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      // A chunk of the list is one index, then one record, per lane.  The first chunk's records are requested here,
+      // alongside the planes; of a later chunk only the index is requested ahead (one register across the light loop
+      // where the record would take eight), the record when the chunk's turn comes.
+      auto fetch_index = [&](uint32_t base) -> uint32_t {
+        uint32_t tq = t;
+        asm volatile("" : "+v"(tq));  // the addresses below are derived per call, not kept in registers across the light loop
+        const uint32_t j = min(base + tq, count - 1u);
+        return tl ? (uint32_t)tl[j] : (cand ? cand[j] : j);
+      };
+      auto fetch_records = [&](uint32_t base, uint32_t idx, float4& lp, float4& lc) {
+        lp = black_pos;
+        lc = black_col;
+        if (base + t < count) {
+          lp = lights[3u * idx];       // pos.xyz, opening_angle (unused)
+          lc = lights[3u * idx + 1u];  // color.xyz, penumbra_angle (unused)
+        }
+      };
+      float4 lp = black_pos, lc = black_col;
+      if (count != 0u) fetch_records(0u, fetch_index(0u), lp, lc);
+      uint32_t width = p.width, full_height = p.full_height;
+      asm volatile("" : "+s"(width), "+s"(full_height));  // their reciprocals are derived per unit, not kept in vector registers
+      const ExactRcp by_width = exact_rcp((float)width), by_height = exact_rcp((float)full_height);
+      Pixel s[2];
+      setup_pixel(s[0], p, clip_coord(w0.xa, by_width), clip_coord(w0.ya + p.row_offset, by_height), dep2.x, mat2.x, nrm.x, nrm.y);
+      setup_pixel(s[1], p, clip_coord(w0.xb, by_width), clip_coord(w0.yb + p.row_offset, by_height), dep2.y, mat2.y, nrm.z, nrm.w);
+      if (!kDeep) {  // the albedo and material words are decoded after the loop: they wait in LDS, one column per lane
+        s_keep_of[0][t] = alb2.x;
+        s_keep_of[1][t] = alb2.y;
+        s_keep_of[2][t] = mat2.x;
+        s_keep_of[3][t] = mat2.y;
+      }
+
+      uint32_t probe_left = kProbeBudget;
+      // a wave whose pixels all have a v.n that is a number <= 1e-6 gets 0 from every light (deferred.comp:43,84) and
+      // does not need to know whether one lay in range: it keeps its ambient colour either way
+      if (__ballot(!(s[0].vn <= kEarlyOut) || !(s[1].vn <= kEarlyOut)) == 0ull) {
+        VKR_COUNT_TRIPS((count + 1u) / 2u, 0u, (count + 1u) / 2u);
+        count = 0u;
+      }
+      uint32_t next_idx = 0;
+      for (uint32_t base = 0; base < count; base += kWaveChunk) {
+        const uint32_t n = min(kWaveChunk, count - base);
+        const uint32_t n2 = (n + 1u) & ~1u;
+        // one wave: its LDS accesses execute in program order, no barrier is needed between the loop's reads of
+        // the previous chunk and these writes
+        if (base != 0u) fetch_records(base, next_idx, lp, lc);
+        s_light[2u * t] = lp;
+        s_light[2u * t + 1u] = lc;
+        Probe probe{probe_budget_for(n2 / 2u, probe_left)};
+        if (base + kWaveChunk < count) next_idx = fetch_index(base + kWaveChunk);  // the next chunk's indices, while this one is shaded
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float4* rec = s_light;
+        float4 pa = rec[0], ca = rec[1], pb = rec[2], cb = rec[3];
+        uint32_t j = 0;
+        for (; j < n2 && probe.budget != 0u; j += 2u) {  // see deferred_kernel: the loop with the test, then the one without
+          const Light AB[2] = {{pa.x, pa.y, pa.z, ca.x, ca.y, ca.z}, {pb.x, pb.y, pb.z, cb.x, cb.y, cb.z}};
+          rec += 4;  // next pair (one pair beyond the list on the last trip: read, never used)
+          shade4<true, true>(
+              s[0], s[1], AB, kc, probe, [&] { pa = rec[0], pb = rec[2]; }, [&] { ca = rec[1], cb = rec[3]; });
+        }
+        if (j < n2) {
+          const float4* rec2 = s_light + 2u * j;
+          float4 pa2 = rec2[0], ca2 = rec2[1], pb2 = rec2[2], cb2 = rec2[3];
+          for (; j < n2; j += 2u) {
+            const Light AB[2] = {{pa2.x, pa2.y, pa2.z, ca2.x, ca2.y, ca2.z}, {pb2.x, pb2.y, pb2.z, cb2.x, cb2.y, cb2.z}};
+            rec2 += 4;
+            pa2 = rec2[0];
+            ca2 = rec2[1];
+            pb2 = rec2[2];
+            cb2 = rec2[3];
+            shade4<true, false>(s[0], s[1], AB, kc, probe, [] {}, [] {});
+          }
+        }
+        probe_left = probe.budget;
+#ifdef VKR_X_COUNT
+        VKR_COUNT_TRIPS(n2 / 2u, probe.skipped, 0u);
+#endif
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      const Where w1 = where(t);
+      float rgb[2][3];
+      if (!kDeep) {
+        finish_pixel(s[0], s_keep_of[0][t], s_keep_of[2][t], s[0].in_range > 0.0f, rgb[0]);
+        finish_pixel(s[1], s_keep_of[1][t], s_keep_of[3][t], s[1].in_range > 0.0f, rgb[1]);
+      } else {
+        finish_pixel(s[0], s_alb[w1.ida], s_mat[w1.ida], s[0].in_range > 0.0f, rgb[0]);
+        finish_pixel(s[1], s_alb[w1.idb], s_mat[w1.idb], s[1].in_range > 0.0f, rgb[1]);
+      }
+      if (!kDeep) {
+        if (w1.ina) {
+          const uint32_t x0 = w1.xa, y = w1.ya;
+          const bool both = w1.inb;
+          uint8_t* orow = p.out + (size_t)y * p.pitch_out;
+          if (kIs8Bit) {
+            uint32_t* o = reinterpret_cast<uint32_t*>(orow) + x0;
+            const uint32_t t0 = pack_unorm8<kOutMode>(rgb[0]), t1 = pack_unorm8<kOutMode>(rgb[1]);
+            if (both)
+              *reinterpret_cast<uint2*>(o) = make_uint2(t0, t1);
+            else
+              o[0] = t0;
+          } else if (kOutMode == kOutRgba16f) {
+            uint2* o = reinterpret_cast<uint2*>(orow) + x0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              if (i == 0 || both) o[i] = half_texel(rgb[i][0], rgb[i][1], rgb[i][2]);
+            }
+          } else {
+            float4* o = reinterpret_cast<float4*>(orow) + x0;
+            o[0] = make_float4(rgb[0][0], rgb[0][1], rgb[0][2], 1.0f);
+            if (both) o[1] = make_float4(rgb[1][0], rgb[1][1], rgb[1][2], 1.0f);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          if (!(i == 0 ? w1.ina : w1.inb)) continue;
+          const uint32_t x = i == 0 ? w1.xa : w1.xb, y = i == 0 ? w1.ya : w1.yb;
+          uint8_t* orow = p.out + (size_t)y * p.pitch_out;
+          if (kIs8Bit)
+            s_out[i == 0 ? w1.ida : w1.idb] = pack_unorm8<kOutMode>(rgb[i]);  // leaves in whole rows, below
+          else if (kOutMode == kOutRgba16f)
+            reinterpret_cast<uint2*>(orow)[x] = half_texel(rgb[i][0], rgb[i][1], rgb[i][2]);
+          else
+            reinterpret_cast<float4*>(orow)[x] = make_float4(rgb[i][0], rgb[i][1], rgb[i][2], 1.0f);
+        }
+      }
+    }
+    }  // pass
+    if (kDeep) {
+      __syncthreads();  // every group's results are in s_out, and nobody reads the planes any more
+      if (kIs8Bit) {
+        uint32_t c = threadIdx.x;
+        asm volatile("" : "+v"(c));
+        const uint32_t r = c >> 3, x4 = (c & 7u) * 4u;
+        const uint32_t gx = tile_x * 32u + x4, gy = tile_y * 32u + r;
+        if (gx < p.width && gy < p.height) {
+          const uint32_t packed[4] = {s_out[r * 32u + x4], s_out[r * 32u + x4 + 1u], s_out[r * 32u + x4 + 2u], s_out[r * 32u + x4 + 3u]};
+          store_rgba8x4(p.out + (size_t)gy * p.pitch_out, gx, min(4u, p.width - gx), packed);
+        }
+      }
+      __syncthreads();  // s_out and the planes are free for the workgroup's next tile
+    }
+  }
+}
+
+// ------------------------------------------------------------------ tile light lists (radius cutoff)
 // One wave per 32 x 32 pixel tile (four tiles per workgroup; nothing is shared between the waves but the queue
 // push at the end).  Lane l owns the 4-pixel groups (4*(l&7) .. +3, (l>>3) + 8k), k = 0..3, of the tile: four
 // 128-bit depth loads and four albedo loads in flight per lane.  The wave derives the tile's bounds from its
@@ -1080,11 +1251,15 @@ __device__ __forceinline__ TileBounds tile_bounds(const DeferredParams& p, uint3
 template <int kOutMode>
 __global__ __launch_bounds__(256) void tile_lists_kernel(const DeferredParams p, const TileListOut o) {
   __shared__ uint32_t s_lit[4], s_class[4];
+  __shared__ uint32_t s_cell[4][64];  // per wave: pixels per depth cell, then where each cell's pixels begin
+  __shared__ uint32_t s_range[4][16];  // per wave: depth range (bit patterns) of each of the eight groups of a deep tile
+  __shared__ uint16_t s_tlist[4][kChunk];  // per wave: the tile's list as it is written out (kChunk = list_cap)
   const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
   const uint32_t n_tiles = p.tiles_x * p.tiles_y;
   const uint32_t tile = blockIdx.x * 4u + wv;
-  if (blockIdx.x == 0u && t <= kListClasses) o.counters_next[t] = 0u;  // queue lengths and ticket of the launch after this one
+  if (blockIdx.x == 0u && t < kListCounterStride) o.counters_next[t] = 0u;  // the counters of the launch after this one
   uint32_t lit_tile = 0xFFFFFFFFu, lit_class = 0u;
+  bool qualifies = false;  // as a deep tile (wave-uniform)
   if (tile < n_tiles) {  // wave-uniform
     const uint32_t tile_y = tile / p.tiles_x, tile_x = tile - tile_y * p.tiles_x;
     const uint32_t x0 = tile_x * 32u + (lane & 7u) * 4u;
@@ -1148,15 +1323,162 @@ __global__ __launch_bounds__(256) void tile_lists_kernel(const DeferredParams p,
         const uint64_t hits = __ballot(hit);
         if (hit) {
           const uint32_t k = count + __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u));
-          if (k < p.list_cap) list[k] = (uint16_t)idx[u];
+          if (k < p.list_cap) {
+            list[k] = (uint16_t)idx[u];
+            s_tlist[wv][k] = (uint16_t)idx[u];
+          }
         }
         count += (uint32_t)__popcll(hits);
       }
     }
-    if (lane == 0u) o.tile_count[tile] = count > p.list_cap ? (count | kTileOverflow) : count;
+    bool deep = false;  // wave-uniform
     if (count != 0u) {
+      // A tile whose pixels span more depth than a light reaches (an object's edge in front of a far background, or
+      // depth that jumps from pixel to pixel) has a list most of whose lights miss most of its pixels.  Such a tile is
+      // shaded in groups of pixels of similar depth, each of which narrows the list to the lights that reach its own
+      // depth range: its pixels are written out grouped by 64 depth cells (a counting sort; the order inside a cell
+      // is whatever the LDS atomics give, which changes the grouping and nothing else - any list that holds the
+      // lights reaching a pixel, in table order, gives that pixel the same bytes).
+      qualifies = count >= kDeepMinList && count <= p.list_cap && b.span > kDeepSpanRadii * sqrt_(p.radius2) && dmax > dmin;
+      deep = qualifies && (p.flags & kFlagNoDeepTiles) == 0u;
+      if (deep) {
+        s_cell[wv][lane] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const float to_cell = 64.0f / (dmax - dmin);
+        uint32_t rank[4][4];
+  #pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float d4[4] = {dep[k].x, dep[k].y, dep[k].z, dep[k].w};
+  #pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const uint32_t cell = min(63u, (uint32_t)((d4[i] - dmin) * to_cell));  // a depth that is not a number lands in cell 0
+            rank[k][i] = cell << 16;
+            if (in[k] && x0 + (uint32_t)i < p.width) rank[k][i] |= atomicAdd(&s_cell[wv][cell], 1u);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t mine = s_cell[wv][lane];
+        uint32_t incl = mine;
+  #pragma unroll
+        for (uint32_t dd = 1; dd < 64u; dd <<= 1) {
+          const uint32_t up = __shfl_up(incl, dd);
+          if (lane >= dd) incl += up;
+        }
+        __builtin_amdgcn_wave_barrier();
+        s_cell[wv][lane] = incl - mine;  // where the cell's pixels begin
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint16_t* __restrict__ order = o.tile_order + (size_t)tile * 1024u;
+  #pragma unroll
+        for (int k = 0; k < 4; ++k) {
+  #pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (in[k] && x0 + (uint32_t)i < p.width)
+              order[s_cell[wv][rank[k][i] >> 16] + (rank[k][i] & 0xFFFFu)] = (uint16_t)((((lane >> 3) + 8u * k) << 5) | ((lane & 7u) * 4u + (uint32_t)i));
+          }
+        }
+        // Depth range of each group of 128 consecutive pixels of that order (depths are not negative: their bit
+        // patterns order like the numbers), then the group's own bounds - the tile's extent on screen, the group's in
+        // depth - and the part of the tile's list that can reach them, in list order.
+        if (lane < 16u) s_range[wv][lane] = (lane & 1u) ? 0u : 0xFFFFFFFFu;  // [2g] = min, [2g + 1] = max, as ordered_bits()
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+  #pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float d4[4] = {dep[k].x, dep[k].y, dep[k].z, dep[k].w};
+  #pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (in[k] && x0 + (uint32_t)i < p.width && d4[i] == d4[i]) {  // a pixel whose depth is not a number is lit by nothing
+              const uint32_t g = (s_cell[wv][rank[k][i] >> 16] + (rank[k][i] & 0xFFFFu)) >> 7;
+              atomicMin(&s_range[wv][2u * g], ordered_bits(d4[i]));
+              atomicMax(&s_range[wv][2u * g + 1u], ordered_bits(d4[i]));
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // All eight groups' boxes at once: lane 8g + 2c + k unprojects corner c of the tile at group g's least (k = 0) or
+        // greatest (k = 1) depth; the box of a group is the hull of its eight points plus the error pad of the positions
+        // (the tile's side faces do not depend on depth: the tile's list has passed them already).
+        float glo[3], ghi[3];
+        {
+          const uint32_t g = lane >> 3, c = (lane >> 1) & 3u;
+          const float gd = from_ordered_bits(s_range[wv][2u * g + (lane & 1u)]);
+          const float xa = (float)(tile_x * 32u) / (float)p.width * 2.0f - 1.0f;
+          const float xb = (float)min(tile_x * 32u + 32u, p.width) / (float)p.width * 2.0f - 1.0f;
+          const float ya = (float)(tile_y * 32u + p.row_offset) / (float)p.full_height * 2.0f - 1.0f;
+          const float yb = (float)(min(tile_y * 32u + 32u, p.height) + p.row_offset) / (float)p.full_height * 2.0f - 1.0f;
+          const float pcx = (c == 1u || c == 2u) ? xb : xa, pcy = (c >= 2u) ? yb : ya;
+          const float* M = p.inv_vp;
+          const float wx = ((M[0] * pcx + M[4] * pcy) + M[8] * gd) + M[12];
+          const float wy = ((M[1] * pcx + M[5] * pcy) + M[9] * gd) + M[13];
+          const float wz = ((M[2] * pcx + M[6] * pcy) + M[10] * gd) + M[14];
+          const float ww = ((M[3] * pcx + M[7] * pcy) + M[11] * gd) + M[15];
+          const float q[3] = {wx / ww, wy / ww, wz / ww};
+          bool ok = (ww > 1e-30f) && (fabsf(q[0]) < 1e30f) && (fabsf(q[1]) < 1e30f) && (fabsf(q[2]) < 1e30f);
+          float terms_w = fabsf(M[3] * pcx) + fabsf(M[7] * pcy) + fabsf(M[11] * gd) + fabsf(M[15]);
+          float terms_xyz = fmaxf(fmaxf(fabsf(M[0] * pcx) + fabsf(M[4] * pcy) + fabsf(M[8] * gd) + fabsf(M[12]),
+                                        fabsf(M[1] * pcx) + fabsf(M[5] * pcy) + fabsf(M[9] * gd) + fabsf(M[13])),
+                                  fabsf(M[2] * pcx) + fabsf(M[6] * pcy) + fabsf(M[10] * gd) + fabsf(M[14]));
+          float min_w = fabsf(ww), scale = 0.0f;
+  #pragma unroll
+          for (int a = 0; a < 3; ++a) glo[a] = ghi[a] = q[a];
+  #pragma unroll
+          for (int off = 1; off <= 4; off <<= 1) {  // over the group's eight lanes
+  #pragma unroll
+            for (int a = 0; a < 3; ++a) {
+              glo[a] = fminf(glo[a], __shfl_xor(glo[a], off));
+              ghi[a] = fmaxf(ghi[a], __shfl_xor(ghi[a], off));
+            }
+            terms_w = fmaxf(terms_w, __shfl_xor(terms_w, off));
+            terms_xyz = fmaxf(terms_xyz, __shfl_xor(terms_xyz, off));
+            min_w = fminf(min_w, __shfl_xor(min_w, off));
+            ok = ok && (__shfl_xor(ok ? 1 : 0, off) != 0);
+          }
+  #pragma unroll
+          for (int a = 0; a < 3; ++a) scale = fmaxf(scale, fmaxf(fabsf(glo[a]), fabsf(ghi[a])));
+          const float pad = position_error_bound(scale, terms_w, terms_xyz, min_w) + 1e-3f;
+  #pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            glo[a] = ok ? glo[a] - pad : -INFINITY;  // bounds that make no sense (a depth range of not-numbers, w <= 0): any light passes
+            ghi[a] = ok ? ghi[a] + pad : INFINITY;
+          }
+        }
+        const uint32_t tile_pixels = min(32u, p.width - tile_x * 32u) * min(32u, p.height - tile_y * 32u);
+        const uint32_t groups = (tile_pixels + 127u) / 128u;
+        uint32_t kept[8] = {};  // wave-uniform
+        for (uint32_t base = 0; base < count; base += 64u) {
+          const uint32_t j = base + lane;
+          const uint32_t idx = s_tlist[wv][min(j, count - 1u)];
+          const float4 q = lights[3u * idx];
+  #pragma unroll
+          for (uint32_t g = 0; g < 8u; ++g) {
+            if (g >= groups) break;  // wave-uniform
+            const float lx = lane_value(glo[0], 8 * g), ly = lane_value(glo[1], 8 * g), lz = lane_value(glo[2], 8 * g);
+            const float hx = lane_value(ghi[0], 8 * g), hy = lane_value(ghi[1], 8 * g), hz = lane_value(ghi[2], 8 * g);
+            const float dx = fmaxf(fmaxf(lx - q.x, q.x - hx), 0.0f);
+            const float dy = fmaxf(fmaxf(ly - q.y, q.y - hy), 0.0f);
+            const float dz = fmaxf(fmaxf(lz - q.z, q.z - hz), 0.0f);
+            const bool hit = (j < count) & ((dx * dx + dy * dy + dz * dz) < p.radius2);
+            const uint64_t hits = __ballot(hit);
+            if (hit) {
+              const uint32_t k = kept[g] + __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u));
+              if (k < kGroupListCap) o.group_list[((size_t)tile * kStripsPerTile + g) * kGroupListCap + k] = (uint16_t)idx;
+            }
+            kept[g] += (uint32_t)__popcll(hits);
+          }
+        }
+        if (lane < groups) {
+          uint32_t mine = 0;
+  #pragma unroll
+          for (uint32_t g = 0; g < 8u; ++g) mine = lane == g ? kept[g] : mine;
+          o.group_count[(size_t)tile * kStripsPerTile + lane] = (uint16_t)(mine > kGroupListCap ? kGroupOverflow : mine);
+        }
+      }
       lit_tile = tile;
-      lit_class = count > p.list_cap ? kListClasses - 1u : list_class(count);
+      lit_class = deep ? kListClasses : (count > p.list_cap ? kListClasses - 1u : list_class(count));
     } else {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -1186,22 +1508,29 @@ __global__ __launch_bounds__(256) void tile_lists_kernel(const DeferredParams p,
         }
       }
     }
+    if (lane == 0u) o.tile_count[tile] = count > p.list_cap ? (count | kTileOverflow) : (deep ? (count | kTileDeep) : count);
   }
   if (lane == 0u) {
     s_lit[wv] = lit_tile;
-    s_class[wv] = lit_class;
+    s_class[wv] = lit_class | (qualifies ? 0x100u : 0u);
   }
   __syncthreads();
-  if (t < kListClasses) {  // thread c queues this workgroup's tiles of class c: one atomic for all of them
+  if (t == kDeepCounter) {  // how many tiles qualify as deep, whether or not this launch treats them so
     uint32_t n = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) n += (s_lit[w] != 0xFFFFFFFFu && s_class[w] == t) ? 1u : 0u;
+    for (int w = 0; w < 4; ++w) n += (s_class[w] >> 8) & 1u;
+    if (n != 0u) atomicAdd(o.counters_now + kDeepCounter, n);
+  }
+  if (t <= kListClasses) {  // thread c queues this workgroup's tiles of class c (kListClasses: the deep tiles): one atomic for all of them
+    uint32_t n = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) n += (s_lit[w] != 0xFFFFFFFFu && (s_class[w] & 0xFFu) == t) ? 1u : 0u;
     if (n != 0u) {
       uint32_t slot = atomicAdd(o.counters_now + t, n);
       uint32_t* queue = o.lit_queue + (size_t)t * n_tiles;
 #pragma unroll
       for (int w = 0; w < 4; ++w)
-        if (s_lit[w] != 0xFFFFFFFFu && s_class[w] == t) queue[slot++] = s_lit[w];
+        if (s_lit[w] != 0xFFFFFFFFu && (s_class[w] & 0xFFu) == t) queue[slot++] = s_lit[w];
     }
   }
 }
@@ -1233,8 +1562,7 @@ __global__ void exact_div_check_kernel(uint32_t n, uint32_t seed, uint32_t* mism
 // order, the lights whose sphere of influence reaches the bin's view pyramid (four side planes through the
 // camera rays of the bin's corners; no depth bounds, so no G-buffer read).  A light is dropped only when it
 // lies outside a side plane by more than radius + pad, where pad covers the binary32 error of the pixel
-// positions it could light: those lie within the radius of the light, so their coordinates are bounded by
-// |light coordinate| + radius (same 2e-3 relative margin as the per-tile bounds).
+// positions it could light (position_error_bound; it grows with the square of the distance from the camera).
 // Measured at 8K x 4096 lights (2040 bins): 16 us, of which 4 us are launch and the plane set-up and 6 us the wait
 // for the scattered index stores at the end.  Requesting the positions of eight trips together (20 us), and a 2 x 2
 // group of bins per workgroup with the plane coefficients in scalar registers (20 us: 510 workgroups leave each
@@ -1291,14 +1619,23 @@ __global__ __launch_bounds__(256) void light_bins_kernel(const DeferredParams p,
   const uint32_t b = blockIdx.y * gridDim.x + blockIdx.x;
   uint32_t* __restrict__ list = bin_list + (size_t)b * L;
   const float radius = sqrt_(p.radius2);
+  const float* M = p.inv_vp;
+  const float terms_w = (fabsf(M[3]) + fabsf(M[7])) + (fabsf(M[11]) + fabsf(M[15]));  // |cx|, |cy|, |depth| <= 1
+  const float terms_xyz = fmaxf(fmaxf((fabsf(M[0]) + fabsf(M[4])) + (fabsf(M[8]) + fabsf(M[12])), (fabsf(M[1]) + fabsf(M[5])) + (fabsf(M[9]) + fabsf(M[13]))),
+                                (fabsf(M[2]) + fabsf(M[6])) + (fabsf(M[10]) + fabsf(M[14])));
   uint32_t count = 0;  // block-uniform
   for (uint32_t base = 0; base < L; base += 256u) {
     const uint32_t i = base + t;
     bool hit = i < L;
     if (hit) {
       const float4 lp = lights[3u * i];
-      const float scale = fmaxf(fmaxf(fabsf(lp.x), fabsf(lp.y)), fabsf(lp.z)) + radius;
-      const float reach = radius + (2e-3f * scale + 1e-2f);
+      // error of the positions the light could reach (position_error_bound): their coordinates are within the radius
+      // of the light's, and 1 / |w| of a pixel's clip-space point is its view depth, at most its distance from the
+      // camera (inverseVP being the inverse of a view-projection centred on cameraPos, as deferred.comp:118 takes it)
+      const float coord = fmaxf(fmaxf(fabsf(lp.x), fabsf(lp.y)), fabsf(lp.z)) + radius;
+      const float ex = lp.x - p.cam[0], ey = lp.y - p.cam[1], ez = lp.z - p.cam[2];
+      const float dist = sqrt_(fma_(ez, ez, fma_(ey, ey, ex * ex))) + radius;
+      const float reach = radius + (kPositionEps * fma_(fma_(coord, terms_w, terms_xyz), dist, coord) + 1e-3f);
 #pragma unroll
       for (int c = 0; c < 4; ++c) hit &= !(((s_face[4 * c] * lp.x + s_face[4 * c + 1] * lp.y) + s_face[4 * c + 2] * lp.z) + s_face[4 * c + 3] > reach);
     }
@@ -1326,7 +1663,7 @@ constexpr uint32_t kListMaxLights = 65536;        // list entries are 16-bit lig
 constexpr uint32_t kFineRounds = VKR_X_FINE_ROUNDS;               // whole-table launches of fewer rounds of four-wave workgroups than this shade one pixel per lane
 
 template <int kOutMode>
-hipError_t launch_mode(const DeferredParams& p, const TileListOut* lists, uint32_t cu_count, hipStream_t stream) {
+hipError_t launch_mode(const DeferredParams& p, const TileListOut* lists, uint32_t cu_count, bool deep_tiles_expected, hipStream_t stream) {
   const dim3 grid((p.width + 31u) / 32u, (p.height + 31u) / 32u, 1u);
   const bool radius = (p.flags & 1u) != 0u;
   // fewer than kFineRounds rounds of four-wave workgroups (four of them fit a CU): one pixel per lane, single-wave workgroups
@@ -1344,7 +1681,7 @@ hipError_t launch_mode(const DeferredParams& p, const TileListOut* lists, uint32
     // the list-shading waves stride over the strips of the lit tiles
     static const uint32_t per_cu = [] {
       int n = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, deferred_list_kernel<kOutMode>, 64, 0) != hipSuccess || n < 1) n = 16;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, deferred_list_kernel<kOutMode, false>, 64, 0) != hipSuccess || n < 1) n = 16;
       return (uint32_t)n;
     }();
     // The list launch is bound by HBM and the shading launch by the vector units, and they run one after the other.
@@ -1355,7 +1692,11 @@ hipError_t launch_mode(const DeferredParams& p, const TileListOut* lists, uint32
     // four grids' worth of waves: the hardware starts the later ones as the earlier ones finish, which evens out
     // what the static deal leaves uneven (measured 8K x 4096 analytic / uncorrelated depth: x1 0.198 / 1.41-1.78 ms,
     // x2 0.189 / 1.36, x4 0.190 / 1.31, x8 0.191 / 1.29, x64 0.231 / 1.34)
-    hipLaunchKernelGGL((deferred_list_kernel<kOutMode>), dim3(min(kStripsPerTile * tiles, cu_count * per_cu * 4u)), dim3(64), 0, stream, p);
+    hipLaunchKernelGGL((deferred_list_kernel<kOutMode, false>), dim3(min(kStripsPerTile * tiles, cu_count * per_cu * 4u)), dim3(64), 0, stream, p);
+    if (deep_tiles_expected) {  // one workgroup of four waves per deep tile; four of them fit a CU
+      if (hipError_t e = hipGetLastError()) return e;
+      hipLaunchKernelGGL((deferred_list_kernel<kOutMode, true>), dim3(min(tiles, cu_count * 4u)), dim3(256), 0, stream, p);
+    }
   }
   return hipGetLastError();
 }
@@ -1407,16 +1748,24 @@ TiledLayout vkr_deferred_tiled_layout(const DeferredParams& p) {
   t.off_tile_count = off;
   off += up(tiles * 4u);
   t.off_lit_queue = off;
-  off += up(tiles * 4u * kListClasses);
+  off += up(tiles * 4u * (kListClasses + 1u));
   t.off_tile_list = off;
   off += up(tiles * t.list_cap * 2u);
+  t.off_tile_order = off;
+  off += up(tiles * 1024u * 2u);
+  t.off_group_list = off;
+  off += up(tiles * 8u * kGroupListCap * 2u);
+  t.off_group_count = off;
+  off += up(tiles * 8u * 2u);
   t.total_bytes = off;
   return t;
 }
 
 hipError_t vkr_launch_deferred(const DeferredParams& params, void* tiled_ws, uint32_t* counters, uint32_t epoch, uint32_t cu_count,
-                               hipStream_t stream) {
+                               bool deep_tiles_expected, uint32_t* deep_hint, hipStream_t stream) {
   DeferredParams p = params;
+  p.deep_hint = deep_hint;
+  p.flags = (p.flags & ~kFlagNoDeepTiles) | (deep_tiles_expected ? 0u : kFlagNoDeepTiles);
   p.bin_list = nullptr;
   p.bin_count = nullptr;
   p.bins_x = 0;
@@ -1424,6 +1773,9 @@ hipError_t vkr_launch_deferred(const DeferredParams& params, void* tiled_ws, uin
   p.tile_count = nullptr;
   p.lit_queue = nullptr;
   p.lit_counters = nullptr;
+  p.tile_order = nullptr;
+  p.group_list = nullptr;
+  p.group_count = nullptr;
   p.tiles_x = (p.width + 31u) / 32u;
   p.tiles_y = (p.height + 31u) / 32u;
   p.list_cap = 0;
@@ -1448,6 +1800,12 @@ hipError_t vkr_launch_deferred(const DeferredParams& params, void* tiled_ws, uin
     lists.lit_queue = reinterpret_cast<uint32_t*>(ws + t.off_lit_queue);
     lists.counters_now = counters + (epoch & 1u) * kListCounterStride;
     lists.counters_next = counters + ((epoch + 1u) & 1u) * kListCounterStride;
+    lists.tile_order = reinterpret_cast<uint16_t*>(ws + t.off_tile_order);
+    p.tile_order = lists.tile_order;
+    lists.group_list = reinterpret_cast<uint16_t*>(ws + t.off_group_list);
+    lists.group_count = reinterpret_cast<uint16_t*>(ws + t.off_group_count);
+    p.group_list = lists.group_list;
+    p.group_count = lists.group_count;
     p.tile_list = lists.tile_list;
     p.tile_count = lists.tile_count;
     p.lit_queue = lists.lit_queue;
@@ -1455,10 +1813,10 @@ hipError_t vkr_launch_deferred(const DeferredParams& params, void* tiled_ws, uin
     p.list_cap = t.list_cap;
   }
   switch (p.out_mode) {
-    case kOutRgba8: return launch_mode<kOutRgba8>(p, use_lists ? &lists : nullptr, cu_count, stream);
-    case kOutBgra8: return launch_mode<kOutBgra8>(p, use_lists ? &lists : nullptr, cu_count, stream);
-    case kOutRgba16f: return launch_mode<kOutRgba16f>(p, use_lists ? &lists : nullptr, cu_count, stream);
-    case kOutRgba32f: return launch_mode<kOutRgba32f>(p, use_lists ? &lists : nullptr, cu_count, stream);
+    case kOutRgba8: return launch_mode<kOutRgba8>(p, use_lists ? &lists : nullptr, cu_count, deep_tiles_expected, stream);
+    case kOutBgra8: return launch_mode<kOutBgra8>(p, use_lists ? &lists : nullptr, cu_count, deep_tiles_expected, stream);
+    case kOutRgba16f: return launch_mode<kOutRgba16f>(p, use_lists ? &lists : nullptr, cu_count, deep_tiles_expected, stream);
+    case kOutRgba32f: return launch_mode<kOutRgba32f>(p, use_lists ? &lists : nullptr, cu_count, deep_tiles_expected, stream);
     default: return hipErrorInvalidValue;
   }
 }

@@ -204,6 +204,10 @@ int32_t run_deferred(vkr_context* ctx, const vkr_deferred_args* a) {
       VKR_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->tile_counters), 256));
       VKR_HIP(hipMemsetAsync(ctx->tile_counters, 0, 256, ctx->stream));
     }
+    if (!ctx->deep_hint && hipHostMalloc(reinterpret_cast<void**>(&ctx->deep_hint), sizeof(uint32_t), hipHostMallocMapped) == hipSuccess) {
+      *ctx->deep_hint = 0xFFFFFFFFu;  // (without the word every tiled call launches the deep-tile kernel: slower by a launch, not wrong)
+      if (hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->deep_hint_device), ctx->deep_hint, 0) != hipSuccess) ctx->deep_hint_device = nullptr;
+    }
     if (layout.total_bytes > ctx->tiled_ws_bytes) {
       // hipFree waits for the device: earlier launches still reading the old lists finish first
       if (ctx->tiled_ws) VKR_HIP(hipFree(ctx->tiled_ws));
@@ -213,7 +217,18 @@ int32_t run_deferred(vkr_context* ctx, const vkr_deferred_args* a) {
       ctx->tiled_ws_bytes = layout.total_bytes;
     }
   }
-  VKR_HIP(vkr_launch_deferred(p, ctx->tiled_ws, ctx->tile_counters, ctx->tile_epoch, (uint32_t)ctx->props.multiProcessorCount, ctx->stream));
+  // the previous frame's number of deep tiles, if it has arrived (vkr_context::deep_hint); unknown counts as "some"
+  const bool deep_expected = layout.tiled && (!ctx->deep_hint || *static_cast<volatile uint32_t*>(ctx->deep_hint) != 0u);
+  const hipError_t launched = vkr_launch_deferred(p, ctx->tiled_ws, ctx->tile_counters, ctx->tile_epoch, (uint32_t)ctx->props.multiProcessorCount, deep_expected, ctx->deep_hint_device, ctx->stream);
+  if (launched != hipSuccess) {
+    if (layout.tiled) {
+      // part of a tiled call may have been enqueued: the queue counters it used must not be taken for zero by the
+      // next call, so both sets are cleared and the alternation starts over
+      (void)hipMemsetAsync(ctx->tile_counters, 0, 256, ctx->stream);
+      ctx->tile_epoch = 0;
+    }
+    return vkr_fail(launched == hipErrorOutOfMemory ? VKR_ERR_OUT_OF_MEMORY : VKR_ERR_DEVICE, "resolve launch: %s", hipGetErrorString(launched));
+  }
   if (layout.tiled) {
     ctx->tile_epoch += 1u;
     ctx->last_tiled = layout;
@@ -424,6 +439,7 @@ int32_t vkr_context_destroy(vkr_context* ctx) {
   if (ctx->cull_state) (void)hipFree(ctx->cull_state);
   if (ctx->tiled_ws) (void)hipFree(ctx->tiled_ws);
   if (ctx->tile_counters) (void)hipFree(ctx->tile_counters);
+  if (ctx->deep_hint) (void)hipHostFree(ctx->deep_hint);
   delete ctx;
   return VKR_OK;
 }
@@ -566,6 +582,9 @@ int32_t vkr_deferred_tile_stats(vkr_context* ctx, vkr_tile_stats* out) {
   const uint8_t* ws = static_cast<const uint8_t*>(ctx->tiled_ws);
   VKR_HIP(hipMemcpyAsync(counts.get(), ws + t.off_tile_count, tiles * 4u, hipMemcpyDeviceToHost, ctx->stream));
   if (t.bins) VKR_HIP(hipMemcpyAsync(bin_counts.get(), ws + t.off_bin_count, t.bins * 4u, hipMemcpyDeviceToHost, ctx->stream));
+  std::unique_ptr<uint16_t[]> kept(new (std::nothrow) uint16_t[tiles * 8u]);  // per group of a deep tile: lights it walked
+  if (!kept) return fail(VKR_ERR_OUT_OF_MEMORY, "out of host memory");
+  VKR_HIP(hipMemcpyAsync(kept.get(), ws + t.off_group_count, tiles * 16u, hipMemcpyDeviceToHost, ctx->stream));
   VKR_HIP(hipStreamSynchronize(ctx->stream));
   out->tiles = (uint32_t)tiles;
   out->list_cap = t.list_cap;
@@ -574,7 +593,7 @@ int32_t vkr_deferred_tile_stats(vkr_context* ctx, vkr_tile_stats* out) {
     for (uint32_t tx = 0; tx < t.tiles_x; ++tx) {
       const uint32_t word = counts[(uint64_t)ty * t.tiles_x + tx];
       const uint64_t px = (uint64_t)std::min(32u, ctx->last_width - tx * 32u) * std::min(32u, ctx->last_height - ty * 32u);
-      uint64_t walked = word;
+      uint64_t walked = word & kTileCountMask;
       if (word == 0u) {
         out->dark_tiles += 1u;
       } else if (word & kTileOverflow) {
@@ -582,7 +601,15 @@ int32_t vkr_deferred_tile_stats(vkr_context* ctx, vkr_tile_stats* out) {
         walked = t.bins ? bin_counts[(uint64_t)(ty * 32u / kBinPixels) * t.bins_x + tx * 32u / kBinPixels] : ctx->last_lights;
       } else {
         out->listed_tiles += 1u;
-        if (word > out->max_list) out->max_list = word;
+        if (walked > out->max_list) out->max_list = (uint32_t)walked;
+        if (word & kTileDeep) {  // its groups of 128 pixels (the last one may be smaller) walked their own narrowed lists
+          out->deep_tiles += 1u;
+          walked = 0;
+          for (uint64_t g = 0; g * 128u < px; ++g) {
+            const uint64_t own = kept[((uint64_t)ty * t.tiles_x + tx) * 8u + g];
+            out->light_pixels += (own == kGroupOverflow ? (uint64_t)(word & kTileCountMask) : own) * std::min<uint64_t>(128u, px - g * 128u);
+          }
+        }
       }
       out->light_pixels += walked * px;
     }

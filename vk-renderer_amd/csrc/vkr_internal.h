@@ -17,6 +17,11 @@ struct vkr_context {
   size_t tiled_ws_bytes = 0;
   uint32_t* tile_counters = nullptr;
   uint32_t tile_epoch = 0;           // tiled launches made so far
+  // Pinned host word into which every tiled call's strips launch stores the number of deep tiles of its frame (nobody
+  // waits for it): by the next call it usually holds the previous frame's figure, which decides whether that call
+  // launches the deep-tile kernel at all.  0xFFFFFFFF: nothing known yet.
+  uint32_t* deep_hint = nullptr;
+  uint32_t* deep_hint_device = nullptr;  // the same word as the device addresses it
   TiledLayout last_tiled{};          // layout, extent and light count of the most recent one (vkr_deferred_tile_stats)
   uint32_t last_width = 0, last_height = 0, last_lights = 0;
   // Single-launch cull: ticket counters + status words (vkr_cull_onepass_bytes), zeroed when (re)allocated and

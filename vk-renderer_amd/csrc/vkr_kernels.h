@@ -21,7 +21,8 @@ struct DeferredParams {
   uint32_t full_height;        // height of the full frame (UV denominator)
   uint32_t light_count;
   uint32_t out_mode;
-  uint32_t flags;              // bit 0: radius cutoff; bit 1: no light lists; bit 2: always four-wave workgroups
+  uint32_t flags;              // bit 0: radius cutoff; bit 1: no light lists; bit 2: always four-wave workgroups;
+                               // bit 3 (set by the launcher): no deep tiles this launch - count them, shade them as strips
   float cam[3];
   float radius2;
   float inv_vp[16];            // column-major
@@ -36,14 +37,22 @@ struct DeferredParams {
   uint32_t list_cap;           // entries per tile list
   const uint16_t* tile_list;   // tiles_x * tiles_y * list_cap
   const uint32_t* tile_count;  // per tile: list length; kTileOverflow set: the list holds only its first list_cap entries
-  const uint32_t* lit_queue;   // kListClasses queues of tiles_x * tiles_y entries: the tiles with a non-empty list, by list class
-  const uint32_t* lit_counters; // [c] = length of queue c; [kListClasses] = ticket counter of the shading launch
+  const uint32_t* lit_queue;   // kListClasses + 1 queues of tiles_x * tiles_y entries: the tiles with a non-empty list, by list class; the last one: the deep tiles
+  const uint32_t* lit_counters; // [c] = length of queue c
+  const uint16_t* tile_order;  // tiles_x * tiles_y * 1024: for tiles marked kTileDeep, their pixels (y << 5 | x within the tile) grouped by depth
+  uint32_t* deep_hint;         // host memory (or null): the strips launch leaves the number of tiles that qualify as deep there
+  const uint16_t* group_list;  // tiles_x * tiles_y * 8 * kGroupListCap: per group of 128 pixels of a deep tile, the entries of the tile's list that can reach it
+  const uint16_t* group_count; // tiles_x * tiles_y * 8: their number; kGroupOverflow: more than a group list holds, the group walks the tile's list
 };
 
 constexpr uint32_t kBinPixels = 128;  // 4 x 4 tiles
 constexpr uint32_t kTileOverflow = 0x80000000u;
+constexpr uint32_t kTileDeep = 0x40000000u;     // the tile spans more depth than a light reaches: it is shaded in groups of pixels of similar depth
+constexpr uint32_t kTileCountMask = 0x3FFFFFFFu;
+constexpr uint32_t kGroupListCap = 128;         // entries per group list
+constexpr uint32_t kGroupOverflow = 0xFFFFu;
 constexpr uint32_t kListClasses = 4;         // queues of lit tiles, by list length
-constexpr uint32_t kListCounterStride = 8;   // words per counter set: kListClasses queue lengths, one ticket, padding
+constexpr uint32_t kListCounterStride = 8;   // words per counter set: kListClasses queue lengths, the deep tiles' queue length, the number of tiles that qualify as deep, padding
 
 // What tile_lists_kernel writes.  Queue lengths and ticket live in one of two counter sets that alternate from one
 // tiled launch of a context to the next: a launch works on counters_now (zero on entry) and zeroes
@@ -54,6 +63,9 @@ struct TileListOut {
   uint32_t* lit_queue;
   uint32_t* counters_now;
   uint32_t* counters_next;
+  uint16_t* tile_order;
+  uint16_t* group_list;
+  uint16_t* group_count;
 };
 
 // Device memory a launch with the radius cutoff and light lists needs (tiled == false: none).
@@ -61,14 +73,19 @@ struct TiledLayout {
   bool tiled;
   uint32_t tiles_x, tiles_y, bins_x, list_cap;
   uint64_t bins, bin_entries;
-  uint64_t off_bin_list, off_bin_count, off_tile_count, off_lit_queue, off_tile_list, total_bytes;
+  uint64_t off_bin_list, off_bin_count, off_tile_count, off_lit_queue, off_tile_list, off_tile_order, off_group_list, off_group_count, total_bytes;
 };
 TiledLayout vkr_deferred_tiled_layout(const DeferredParams& p);
 // tiled_ws: total_bytes of 256-byte-aligned device memory when the layout says tiled, else ignored.
 // counters: 2 x kListCounterStride device words, zero before the context's first tiled launch; epoch: number of tiled launches the
 // context has made so far.  cu_count sizes the grid of the list-shading launch (workgroups that stay resident).
+// deep_tiles_expected: whether to launch the kernel that shades deep tiles (see kTileDeep); false makes the listing
+// launch treat every tile as an ordinary one.  Either way counters[set of this launch][kDeepCounter] ends up as the number of
+// tiles that qualify.
+constexpr uint32_t kDeepCounter = 5;
+constexpr uint32_t kFlagNoDeepTiles = 8u;
 hipError_t vkr_launch_deferred(const DeferredParams& p, void* tiled_ws, uint32_t* counters, uint32_t epoch, uint32_t cu_count,
-                               hipStream_t stream);
+                               bool deep_tiles_expected, uint32_t* deep_hint, hipStream_t stream);
 hipError_t vkr_launch_exact_div_check(uint32_t n, uint32_t seed, uint32_t* mismatches, hipStream_t stream);
 
 struct DrawCmd {
