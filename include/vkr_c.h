@@ -209,9 +209,16 @@ typedef struct vkr_cull_args {
   vkr_draw_indexed_indirect_command* cmd_out;              /* device: M */
   uint32_t* visible;        /* device: N */
   uint32_t* error_flag;     /* device, optional: set to 1 if an instance names a mesh outside this call (or, in the
-                               deterministic mode, if the launch could not keep its workgroups resident together) */
+                               deterministic mode, if a workgroup stopped waiting for another one: see below) */
 } vkr_cull_args;
 
+/* Deterministic mode and other work on the GPU.  Its workgroups wait for status words of lower-numbered
+ * workgroups of the same launch.  On a GPU that other streams or contexts keep busy some of them get their places
+ * late, and the others wait for as long as that takes - the call gets slower, never wrong.  Only when an awaited
+ * workgroup has not run for 10 s of wall clock (a device fault, foreign work that never ends) does a workgroup stop
+ * waiting, so that the GPU is not held for ever; the launch's results are then invalid, error_flag (if given) is
+ * set, and the next call on this context that waits for the stream - vkr_queue_wait_idle, vkr_buffer_download,
+ * vkr_fence_wait, vkr_fence_status when signalled - returns VKR_ERR_DEVICE once, naming the launch. */
 VKR_API int32_t vkr_prep_indirect(vkr_context* ctx, const vkr_cull_args* args);
 
 /* No counterpart in the reference.  For callers that cannot allocate device memory or let a library do it
@@ -221,9 +228,11 @@ VKR_API int32_t vkr_prep_indirect(vkr_context* ctx, const vkr_cull_args* args);
  * address is resolved once per GPU inside vkr_context_create).  Same arguments and results as
  * vkr_prep_indirect; VKR_CULL_DETERMINISTIC is implied.  The call makes no hipMalloc / hipFree or other
  * allocating call.  VKR_ERR_INVALID_ARGUMENT if instance_count > VKR_NOALLOC_MAX_INSTANCES.
- * All calls on one GPU share the one array: two calls whose kernels could overlap on a GPU (different
- * contexts, or threads of one process on the same device) race; calls on one context are stream-ordered and
- * safe.  The array keeps the previous call's words; each call tags its words with a sequence number of its
+ * All calls on one GPU share the one array, whatever their context or host thread: the library orders them (an
+ * event recorded behind each launch and waited for, on the GPU, in front of the next), so they never overlap
+ * each other; replays of a recorded call (below) are outside that ordering, and a replay that may run at the
+ * same time as another user of the array on the same GPU races with it - order those yourself.
+ * The array keeps the previous call's words; each call tags its words with a sequence number of its
  * own, so nothing has to be cleared (the library zeroes the array when the numbers wrap, after 2^30 calls).
  * Called while the context's stream (vkr_context_stream) is being captured into a HIP graph, the call records
  * two nodes: a clear of the array and the launch, tagged with a number reserved for recorded launches - a

@@ -77,3 +77,52 @@ def test_two_contexts_alternate(vkr, synth, oracle):
         ctx = (c1, c2)[step & 1]
         _cull_once(vkr, oracle, ctx, synth, (50000, 3000, 200000, 700)[step % 4], (40, 7, 100, 3)[step % 4], step, ("noalloc", "deterministic")[(step >> 1) & 1])
         _tiled_once(vkr, ctx, synth, (200, 96)[step & 1], (120, 70)[step & 1], 400, 30.0, step, vkr.FORMAT_R8G8B8A8_UNORM)
+
+
+def test_deterministic_cull_beside_a_long_resolve(vkr, synth, oracle):
+    """Two contexts of one process at work on the GPU at the same time: context A shades a 4K frame against a table
+    of 12288 lights (over 100 ms, every wave slot taken) while context B makes deterministic culls of 2^22
+    instances on its own stream.  The cull's workgroups wait for each other's status words and get their places
+    only as A's workgroups retire: the waits must simply last (they are bounded by the wall clock, in seconds),
+    and every list and command buffer must be the oracle's, with no error reported by either channel."""
+    a, b = vkr.Context(0), vkr.Context(0)
+    case = synth.deferred_case(3840, 2160, 256, config_index=1)
+    table = np.tile(case["lights"], (48, 1))
+    gb = vkr.GBuffer(a, 3840, 2160).upload(case["gbuf"])
+    lights = a.buffer_from(table)
+    out = a.image(vkr.FORMAT_R8G8B8A8_UNORM, 3840, 2160)
+    args = vkr.make_deferred_args(gb, out, lights, table.shape[0], case["push"])
+    scene = synth.cull_case(1 << 22, 1024, config_index=1)
+    ref = oracle.cull(scene["aabb_min"], scene["aabb_max"], scene["planes"], scene["mesh_base"], scene["cmd_template"])
+    cs = vkr.CullScene(b, scene["aabb_min"], scene["aabb_max"], scene["mesh_base"], scene["cmd_template"])
+    small = synth.cull_case(70000, 30, config_index=4)
+    ref_small = oracle.cull(small["aabb_min"], small["aabb_max"], small["planes"], small["mesh_base"], small["cmd_template"])
+    cs_small = vkr.CullScene(b, small["aabb_min"], small["aabb_max"], small["mesh_base"], small["cmd_template"])
+    a.deferred_resolve(args)  # warm: code objects loaded, clocks up
+    cs.run(scene["planes"], vkr.CULL_DETERMINISTIC)
+    a.wait_idle()
+    b.wait_idle()
+    overlapped = 0
+    for round_ in range(3):
+        for c in (cs, cs_small):
+            c.visible.fill_u32(0xFFFFFFFF)
+            c.cmd_out.fill_u32(0xDEADBEEF, 0, c.m * 20 // 4 * 4)
+            c.error_flag.fill_u32(0)
+        b.wait_idle()
+        a.deferred_resolve(args)
+        busy = a.marker()
+        for _ in range(3):  # several launches while A is busy: each has to get through on its own
+            b.prep_indirect(cs.args(scene["planes"], vkr.CULL_DETERMINISTIC))
+            if round_ == 1:
+                b.prep_indirect_noalloc(cs_small.args(small["planes"], 0))
+            else:
+                b.prep_indirect(cs_small.args(small["planes"], vkr.CULL_DETERMINISTIC))
+        b.wait_idle()  # raises if a launch gave up its wait
+        overlapped += not busy.signaled()
+        a.wait_idle()
+        for c, r in ((cs, ref), (cs_small, ref_small)):
+            res = c.results()
+            assert res["error"] == 0
+            assert res["cmds"].tobytes() == r["cmds"].tobytes()
+            assert np.array_equal(res["visible"], r["visible"])
+    print(f"culls finished while the resolve was still running in {overlapped} of 3 rounds")

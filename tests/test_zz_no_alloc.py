@@ -44,15 +44,65 @@ def test_two_calls_in_a_row_second_smaller(vkr, synth, oracle, ctx):
         assert 0 < int(ref["mask"].sum()) < scene["aabb_min"].shape[0]
 
 
-def test_largest_accepted_size_then_a_ragged_one(vkr, synth, ctx):
+def _free_device_bytes():
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    free, total = C.c_size_t(), C.c_size_t()
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value
+
+
+def test_largest_accepted_size_then_a_ragged_one(vkr, synth, oracle, ctx):
     n = vkr.NOALLOC_MAX_INSTANCES
     scene = synth.cull_case(n, 1024, config_index=2)
     want, got = _both(vkr, ctx, scene, scene["planes"])
     _same(want, got)
     assert 0.05 < int(got["cmds"]["instanceCount"].sum()) / n < 0.5
+    ref = oracle.cull(scene["aabb_min"], scene["aabb_max"], scene["planes"], scene["mesh_base"], scene["cmd_template"])
+    assert got["cmds"].tobytes() == ref["cmds"].tobytes() and np.array_equal(got["visible"], ref["visible"])
     ragged = synth.cull_case(1025, 5, config_index=3)
     want, got = _both(vkr, ctx, ragged, ragged["planes"])
     _same(want, got)
+
+
+def test_calls_leave_the_free_device_memory_as_it_was(vkr, synth, ctx):
+    """hipMemGetInfo before and after calls of every accepted size class, the largest included: not a byte taken
+    ."""
+    scenes = [synth.cull_case(n, m, config_index=2) for n, m in ((vkr.NOALLOC_MAX_INSTANCES, 1024), (70000, 30), (1, 1))]
+    sets = [vkr.CullScene(ctx, sc["aabb_min"], sc["aabb_max"], sc["mesh_base"], sc["cmd_template"]) for sc in scenes]
+    sets[1].run(scenes[1]["planes"], 0)  # (the atomic mode: loads nothing the calls below could be charged with)
+    ctx.wait_idle()
+    before = _free_device_bytes()
+    for _ in range(3):
+        for cs, sc in zip(sets, scenes):
+            ctx.prep_indirect_noalloc(cs.args(sc["planes"], 0))
+    ctx.wait_idle()
+    assert _free_device_bytes() == before
+    block = ctx.buffer(64 << 20)
+    assert _free_device_bytes() <= before - (64 << 20)  # the measurement does see an allocation when there is one
+    block.destroy()
+
+
+def test_calls_from_two_contexts_without_a_wait_in_between(vkr, synth, oracle):
+    """Every call on a GPU uses the one array, whatever its context: the library makes each launch wait for the one
+    before, so two contexts (two streams) may issue calls back to back and still get the oracle's lists."""
+    c1, c2 = vkr.Context(0), vkr.Context(0)
+    work = []
+    for ctx, (n, m, seed) in ((c1, (1 << 21, 500, 1)), (c2, (1 << 20, 64, 2)), (c1, (300000, 7, 3)), (c2, (1 << 21, 900, 4))):
+        sc = synth.cull_case(n, m, config_index=seed)
+        cs = vkr.CullScene(ctx, sc["aabb_min"], sc["aabb_max"], sc["mesh_base"], sc["cmd_template"])
+        cs.visible.fill_u32(0xFFFFFFFF)
+        work.append((ctx, sc, cs, oracle.cull(sc["aabb_min"], sc["aabb_max"], sc["planes"], sc["mesh_base"], sc["cmd_template"])))
+    c1.wait_idle()
+    c2.wait_idle()
+    for _ in range(4):
+        for ctx, sc, cs, _ref in work:
+            ctx.prep_indirect_noalloc(cs.args(sc["planes"], 0))
+    c1.wait_idle()
+    c2.wait_idle()
+    for _ctx, _sc, cs, ref in work:
+        res = cs.results()
+        assert res["error"] == 0 and res["cmds"].tobytes() == ref["cmds"].tobytes() and np.array_equal(res["visible"], ref["visible"])
 
 
 def test_instance_range_arguments(vkr, synth, ctx):

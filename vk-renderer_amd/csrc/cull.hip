@@ -230,11 +230,18 @@ __device__ __forceinline__ uint32_t mesh_holding(const CullParams& p, uint32_t i
 // The words carry the call's sequence number, so a word left by an earlier call reads as "not yet published"
 // and nothing has to be cleared between calls.  Status words are written and polled with relaxed agent-scope
 // atomics (the value is the message: no other memory has to become visible between workgroups).
-// A block waits only for lower-numbered blocks, whose first word is published before anything waits on their
-// behalf, and the grid is no larger than what the device holds at once, so every block a wait depends on is
-// being worked on: the waits end.  Should a predecessor never show up all the same (a grid that is not fully
-// resident because something else occupies the device), the wait gives up after kMaxPolls polls and reports
-// through error_flag rather than hang the GPU.
+// Why the waits end.  A block waits only for lower-numbered blocks, and every workgroup publishes its block's
+// first word before it waits for anything, so a wait can only be for a block whose workgroup has not got that far
+// yet.  With the device to itself the whole grid is resident (it is sized for that) and that is a matter of
+// microseconds.  When other work holds part of the device - another context's kernel, another stream - a
+// workgroup of this grid may still be waiting for a place while later-numbered ones (dispatched to a compute die
+// with room) already poll its word: it gets its place when a workgroup of the other kernel retires, so the wait is
+// as long as the other kernel's workgroups take, and ends.  The wait is therefore bounded by the wall clock, not by
+// a number of polls: only after kCullPatienceSeconds without the awaited word - the other workgroups cannot run at
+// all: a device fault, or foreign work that itself never ends - does a workgroup stop waiting, so that the GPU is
+// not held for ever.  The launch's results are then wrong, and it says so twice: through error_flag (if given) and
+// through the context's fault word in host memory, which every synchronising call of the library checks and
+// reports as VKR_ERR_DEVICE.
 // The command of mesh m is written by the block in which the mesh ends.
 // Measured at 2^22 instances, 1024 meshes: 32.5 us per call, against 37.5 us for the former mask launch +
 // placement launch.  One workgroup per block with the look-back straight after the tests measured 39-41 us (the
@@ -249,7 +256,6 @@ __device__ __forceinline__ uint32_t mesh_holding(const CullParams& p, uint32_t i
 // made the compiler copy the block to scratch memory, and fetching them from LDS per trip raised the count to 79.
 
 constexpr uint32_t kKindAggregate = 1u, kKindPrefix = 2u;
-constexpr uint32_t kMaxPolls = 1u << 20;  // a predecessor that never publishes (it cannot, short of a fault) ends the wait
 
 __device__ __forceinline__ void publish_status(uint64_t* slot, uint32_t seq, uint32_t kind, uint32_t value) {
   __hip_atomic_store(slot, ((uint64_t)((seq << 2) | kind) << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -306,12 +312,19 @@ __global__ __launch_bounds__(256) void cull_onepass_kernel(const CullParams p, c
         uint64_t v = 0;
         if (j >= 0) {
           uint32_t polls = 0;
+          uint64_t since = 0;  // wall clock at the 1024th poll in vain
           v = have_first ? first_poll : poll(j);
           while ((uint32_t)(v >> 34) != o.seq) {
-            if (++polls >= kMaxPolls) {
-              bad = true;
-              v = ((uint64_t)((o.seq << 2) | kKindPrefix) << 32);  // give up: count nothing from here back
-              break;
+            if ((++polls & 1023u) == 0u) {
+              const uint64_t now = (uint64_t)wall_clock64();
+              if (since == 0ull) {
+                since = now | 1ull;
+              } else if (now - since > o.patience_ticks) {  // the awaited workgroup cannot run: stop, and say so
+                bad = true;
+                if (o.fault) __hip_atomic_store(o.fault, o.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                v = ((uint64_t)((o.seq << 2) | kKindPrefix) << 32);
+                break;
+              }
             }
             __builtin_amdgcn_s_sleep(2);
             v = poll(j);
@@ -520,7 +533,8 @@ namespace {
 constexpr int kMaxDevices = 64;
 struct StaticState {
   void* ptr = nullptr;
-  uint32_t seq = 0;  // sequence number of the most recent call that used the array
+  hipEvent_t last_use = nullptr;  // recorded behind the most recent launch that used the array
+  uint32_t seq = 0;               // sequence number of that launch
 };
 std::mutex g_scratch_mutex;
 StaticState g_scratch[kMaxDevices];
@@ -529,26 +543,19 @@ StaticState g_scratch[kMaxDevices];
 hipError_t vkr_cull_static_init(int device) {
   if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
   std::lock_guard<std::mutex> lock(g_scratch_mutex);
-  if (g_scratch[device].ptr) return hipSuccess;
-  void* ptr = nullptr;
-  const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));  // the address on the current device
-  if (e != hipSuccess) return e;
-  if (!ptr || (reinterpret_cast<uintptr_t>(ptr) & 255u)) return hipErrorInvalidSymbol;
-  g_scratch[device].ptr = ptr;
-  return hipSuccess;
-}
-
-void* vkr_cull_static_state(int device, uint64_t* out_bytes, uint32_t* out_seq, bool* out_clear_first) {
-  if (out_bytes) *out_bytes = kScratchBytes;
-  if (device < 0 || device >= kMaxDevices) return nullptr;
-  std::lock_guard<std::mutex> lock(g_scratch_mutex);
   StaticState& st = g_scratch[device];
-  if (!st.ptr) return nullptr;
-  const bool wrap = st.seq + 1u >= kCullSeqRecorded;
-  st.seq = wrap ? 1u : st.seq + 1u;
-  if (out_seq) *out_seq = st.seq;
-  if (out_clear_first) *out_clear_first = wrap;
-  return st.ptr;
+  if (!st.ptr) {
+    void* ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));  // the address on the current device
+    if (e != hipSuccess) return e;
+    if (!ptr || (reinterpret_cast<uintptr_t>(ptr) & 255u)) return hipErrorInvalidSymbol;
+    st.ptr = ptr;
+  }
+  if (!st.last_use) {
+    const hipError_t e = hipEventCreateWithFlags(&st.last_use, hipEventDisableTiming);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 uint64_t vkr_cull_state_bytes(uint64_t instance_count) {
@@ -565,7 +572,18 @@ uint32_t vkr_cull_blocks_per_cu() {
   return per_cu;
 }
 
-hipError_t vkr_launch_cull_deterministic(const CullParams& p, void* state_mem, uint32_t seq, uint32_t resident_blocks, hipStream_t stream) {
+namespace {
+uint64_t patience_ticks() {  // kCullPatienceSeconds on the device's wall clock (100 MHz where the attribute is missing)
+  static const uint64_t ticks = [] {
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
+    return (uint64_t)khz * 1000ull * kCullPatienceSeconds;
+  }();
+  return ticks;
+}
+}  // namespace
+
+hipError_t vkr_launch_cull_deterministic(const CullParams& p, void* state_mem, uint32_t seq, uint32_t resident_blocks, uint32_t* fault, hipStream_t stream) {
   if (p.mesh_count == 0u) return hipSuccess;
   const uint32_t nblk = (p.instance_count + kBlockInstances - 1u) / kBlockInstances;
   if (nblk == 0u) {
@@ -575,11 +593,36 @@ hipError_t vkr_launch_cull_deterministic(const CullParams& p, void* state_mem, u
   if (!state_mem || seq == 0u || seq >= kCullSeqEnd || resident_blocks == 0u) return hipErrorInvalidValue;
   OnePassState o;
   o.status = static_cast<uint64_t*>(state_mem);
+  o.fault = fault;
+  o.patience_ticks = patience_ticks();
   o.seq = seq;
-  // every workgroup of the grid must be resident at once: a block waits for lower-numbered blocks, which other
-  // workgroups hold
+  // a grid the idle device holds whole: a block's predecessors are then all at work (see the kernel's comment for
+  // what happens when the device is not idle)
   hipLaunchKernelGGL(cull_onepass_kernel, dim3(min(nblk, resident_blocks)), dim3(kBlockThreads), 0, stream, p, o, nblk);
   return hipGetLastError();
+}
+
+hipError_t vkr_launch_cull_static(const CullParams& p, int device, uint32_t resident_blocks, uint32_t* fault, hipStream_t stream) {
+  if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+  if (vkr_cull_state_bytes(p.instance_count) > kScratchBytes) return hipErrorInvalidValue;
+  // the capture state first: a recorded launch draws no sequence number and leaves the counter as it is
+  hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+  hipError_t e = hipStreamIsCapturing(stream, &capture);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);  // wait, launch and record stay together: event order = array order
+  StaticState& st = g_scratch[device];
+  if (!st.ptr || !st.last_use) return hipErrorNotInitialized;
+  if (capture != hipStreamCaptureStatusNone) {
+    if ((e = hipMemsetAsync(st.ptr, 0, kScratchBytes, stream)) != hipSuccess) return e;
+    return vkr_launch_cull_deterministic(p, st.ptr, kCullSeqRecorded, resident_blocks, fault, stream);
+  }
+  if ((e = hipStreamWaitEvent(stream, st.last_use, 0)) != hipSuccess) return e;  // (an event never recorded counts as done)
+  const bool wrap = st.seq + 1u >= kCullSeqRecorded;
+  if (wrap && (e = hipMemsetAsync(st.ptr, 0, kScratchBytes, stream)) != hipSuccess) return e;
+  st.seq = wrap ? 1u : st.seq + 1u;
+  e = vkr_launch_cull_deterministic(p, st.ptr, st.seq, resident_blocks, fault, stream);
+  const hipError_t r = hipEventRecord(st.last_use, stream);  // also after a failed launch: whatever was enqueued is ordered
+  return e != hipSuccess ? e : r;
 }
 
 hipError_t vkr_launch_cull_atomic(const CullParams& p, hipStream_t stream) {

@@ -204,7 +204,7 @@ int32_t run_deferred(vkr_context* ctx, const vkr_deferred_args* a) {
       VKR_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->tile_counters), 256));
       VKR_HIP(hipMemsetAsync(ctx->tile_counters, 0, 256, ctx->stream));
     }
-    if (!ctx->deep_hint && hipHostMalloc(reinterpret_cast<void**>(&ctx->deep_hint), sizeof(uint32_t), hipHostMallocMapped) == hipSuccess) {
+    if (!ctx->deep_hint && hipHostMalloc(reinterpret_cast<void**>(&ctx->deep_hint), sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
       *ctx->deep_hint = 0xFFFFFFFFu;  // (without the word every tiled call launches the deep-tile kernel: slower by a launch, not wrong)
       if (hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->deep_hint_device), ctx->deep_hint, 0) != hipSuccess) ctx->deep_hint_device = nullptr;
     }
@@ -271,22 +271,10 @@ int32_t run_cull(vkr_context* ctx, const vkr_cull_args* a, bool static_state = f
   const uint32_t resident = (uint32_t)ctx->props.multiProcessorCount * vkr_cull_blocks_per_cu();
   const uint64_t need = vkr_cull_state_bytes(a->instance_count);
   if (static_state) {
-    uint64_t bytes = 0;
-    uint32_t seq = 0;
-    bool clear_first = false;
-    void* state = vkr_cull_static_state(ctx->device, &bytes, &seq, &clear_first);
-    if (!state) return fail(VKR_ERR_BAD_STATE, "vkr_prep_indirect_noalloc: the static state of device %d was not resolved at context creation", ctx->device);
-    if (need > bytes) return fail(VKR_ERR_INVALID_ARGUMENT, "static state too small for %llu instances", (unsigned long long)a->instance_count);
-    // Under stream capture the launch becomes a graph node that runs again, unchanged, at every replay: it gets
-    // the sequence number reserved for recorded launches and a clear of the array in front of it (also recorded).
-    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
-    VKR_HIP(hipStreamIsCapturing(ctx->stream, &capture));
-    if (capture != hipStreamCaptureStatusNone) {
-      seq = kCullSeqRecorded;
-      clear_first = true;
-    }
-    if (clear_first) VKR_HIP(hipMemsetAsync(state, 0, bytes, ctx->stream));
-    VKR_HIP(vkr_launch_cull_deterministic(p, state, seq, resident, ctx->stream));
+    const hipError_t e = vkr_launch_cull_static(p, ctx->device, resident, ctx->cull_fault_device, ctx->stream);
+    if (e == hipErrorNotInitialized) return fail(VKR_ERR_BAD_STATE, "vkr_prep_indirect_noalloc: the static state of device %d was not resolved at context creation", ctx->device);
+    if (e == hipErrorInvalidValue) return fail(VKR_ERR_INVALID_ARGUMENT, "static state too small for %llu instances", (unsigned long long)a->instance_count);
+    VKR_HIP(e);
   } else if (a->flags & VKR_CULL_DETERMINISTIC) {
     if (stream_is_recording(ctx))
       return fail(VKR_ERR_BAD_STATE, "the deterministic cull keeps per-call state on the host and cannot be recorded into a HIP graph: use vkr_prep_indirect_noalloc");
@@ -304,7 +292,7 @@ int32_t run_cull(vkr_context* ctx, const vkr_cull_args* a, bool static_state = f
       ctx->cull_seq = 0;
     }
     ctx->cull_seq += 1u;
-    VKR_HIP(vkr_launch_cull_deterministic(p, ctx->cull_state, ctx->cull_seq, resident, ctx->stream));
+    VKR_HIP(vkr_launch_cull_deterministic(p, ctx->cull_state, ctx->cull_seq, resident, ctx->cull_fault_device, ctx->stream));
   } else {
     VKR_HIP(vkr_launch_cull_atomic(p, ctx->stream));
   }
@@ -401,6 +389,14 @@ int32_t vkr_fail(int32_t code, const char* fmt, ...) {
   return code;
 }
 
+int32_t vkr_check_cull_fault(vkr_context* ctx) {
+  if (!ctx || !ctx->cull_fault) return VKR_OK;
+  const uint32_t seq = __atomic_exchange_n(ctx->cull_fault, 0u, __ATOMIC_RELAXED);
+  if (seq == 0u) return VKR_OK;
+  return vkr_fail(VKR_ERR_DEVICE, "a deterministic cull on this context (launch %u) stopped waiting for one of its own workgroups after %u s: "
+                  "the device did not run them; visible[] and cmd_out[] of the deterministic culls since the last wait are invalid", seq, kCullPatienceSeconds);
+}
+
 extern "C" {
 
 const char* vkr_last_error(void) { return g_last_error; }
@@ -424,7 +420,17 @@ int32_t vkr_context_create(int32_t device_ordinal, vkr_context** out_ctx) {
   // triggers a first-use code object load (which allocates) on this device
   VKR_HIP(vkr_cull_static_init(device_ordinal));
   (void)vkr_cull_blocks_per_cu();  // occupancy query of the deterministic cull, made here rather than inside a call
-  VKR_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  if (hipHostMalloc(reinterpret_cast<void**>(&ctx->cull_fault), sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+      hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->cull_fault_device), ctx->cull_fault, 0) != hipSuccess) {
+    if (ctx->cull_fault) (void)hipHostFree(ctx->cull_fault);
+    return fail(VKR_ERR_OUT_OF_MEMORY, "no pinned host word for the context");
+  }
+  *ctx->cull_fault = 0u;
+  const hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (se != hipSuccess) {
+    (void)hipHostFree(ctx->cull_fault);
+    return fail(VKR_ERR_DEVICE, "hipStreamCreateWithFlags: %s", hipGetErrorString(se));
+  }
   *out_ctx = ctx.release();
   return VKR_OK;
 }
@@ -440,6 +446,7 @@ int32_t vkr_context_destroy(vkr_context* ctx) {
   if (ctx->tiled_ws) (void)hipFree(ctx->tiled_ws);
   if (ctx->tile_counters) (void)hipFree(ctx->tile_counters);
   if (ctx->deep_hint) (void)hipHostFree(ctx->deep_hint);
+  if (ctx->cull_fault) (void)hipHostFree(ctx->cull_fault);
   delete ctx;
   return VKR_OK;
 }
@@ -554,7 +561,7 @@ int32_t vkr_buffer_download(vkr_buffer* buf, uint64_t offset, void* dst, uint64_
   VKR_HIP(hipSetDevice(buf->ctx->device));
   VKR_HIP(hipMemcpyAsync(dst, static_cast<uint8_t*>(buf->device) + offset, bytes, hipMemcpyDeviceToHost, buf->ctx->stream));
   VKR_HIP(hipStreamSynchronize(buf->ctx->stream));
-  return VKR_OK;
+  return vkr_check_cull_fault(buf->ctx);
 }
 
 int32_t vkr_buffer_fill_u32(vkr_buffer* buf, uint64_t offset, uint32_t value, uint64_t bytes) {
@@ -753,13 +760,13 @@ int32_t vkr_queue_wait_idle(vkr_context* ctx) {
   if (!ctx) return fail(VKR_ERR_INVALID_ARGUMENT, "null context");
   VKR_HIP(hipSetDevice(ctx->device));
   VKR_HIP(hipStreamSynchronize(ctx->stream));
-  return VKR_OK;
+  return vkr_check_cull_fault(ctx);
 }
 
 int32_t vkr_fence_status(vkr_fence* fence) {
   if (!fence) return fail(VKR_ERR_INVALID_ARGUMENT, "null fence");
   const hipError_t e = hipEventQuery(fence->event);
-  if (e == hipSuccess) return VKR_OK;
+  if (e == hipSuccess) return vkr_check_cull_fault(fence->ctx);
   if (e == hipErrorNotReady) return VKR_ERR_NOT_READY;
   return fail(VKR_ERR_DEVICE, "hipEventQuery: %s", hipGetErrorString(e));
 }
@@ -768,12 +775,12 @@ int32_t vkr_fence_wait(vkr_fence* fence, uint64_t timeout_ns) {
   if (!fence) return fail(VKR_ERR_INVALID_ARGUMENT, "null fence");
   if (timeout_ns == UINT64_MAX) {
     VKR_HIP(hipEventSynchronize(fence->event));
-    return VKR_OK;
+    return vkr_check_cull_fault(fence->ctx);
   }
   const auto deadline = std::chrono::steady_clock::now() + std::chrono::nanoseconds(timeout_ns);
   for (;;) {
     const hipError_t e = hipEventQuery(fence->event);
-    if (e == hipSuccess) return VKR_OK;
+    if (e == hipSuccess) return vkr_check_cull_fault(fence->ctx);
     if (e != hipErrorNotReady) return fail(VKR_ERR_DEVICE, "hipEventQuery: %s", hipGetErrorString(e));
     if (std::chrono::steady_clock::now() >= deadline) return VKR_ERR_NOT_READY;
     std::this_thread::yield();

@@ -29,7 +29,15 @@ struct vkr_context {
   void* cull_state = nullptr;
   size_t cull_state_bytes = 0;
   uint32_t cull_seq = 0;
+  // Pinned host word that a deterministic cull sets when a workgroup abandoned its wait (kCullPatienceSeconds): the
+  // results of that launch are wrong.  Allocated with the context; checked, reported and cleared by every library
+  // call that waits for the stream.
+  uint32_t* cull_fault = nullptr;
+  uint32_t* cull_fault_device = nullptr;  // the same word as the device addresses it
 };
+
+// After a wait for the context's stream: VKR_ERR_DEVICE once if a deterministic cull since the last check gave up.
+int32_t vkr_check_cull_fault(vkr_context* ctx);
 
 // Records the message returned by vkr_last_error() for the calling thread and returns `code`.
 int32_t vkr_fail(int32_t code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));

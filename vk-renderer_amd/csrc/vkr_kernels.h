@@ -114,10 +114,15 @@ struct CullParams {
 // seq: 1 .. kCullSeqEnd - 1, different from the seq of every earlier call on the same state since it was last
 // zeroed.  resident_blocks: how many workgroups of the kernel the device holds at once
 // (vkr_cull_blocks_per_cu() x CUs, or fewer); the grid never exceeds it.
+// fault: a word in host memory (device address, may be null) that a launch sets to its seq when a workgroup
+// abandons the wait for another one (after kCullPatienceSeconds: the results of that launch are wrong).
 struct OnePassState {
   uint64_t* status;
+  uint32_t* fault;
+  uint64_t patience_ticks;  // of the device's wall clock
   uint32_t seq;
 };
+constexpr uint32_t kCullPatienceSeconds = 10;
 constexpr uint32_t kCullSeqEnd = 1u << 30;
 // A launch recorded into a HIP graph runs again with the arguments it was recorded with, sequence number
 // included, so it cannot rely on "different from every earlier call": recorded launches all use this number,
@@ -126,13 +131,19 @@ constexpr uint32_t kCullSeqRecorded = kCullSeqEnd - 1u;
 uint64_t vkr_cull_state_bytes(uint64_t instance_count);
 uint32_t vkr_cull_blocks_per_cu();
 hipError_t vkr_launch_cull_atomic(const CullParams& p, hipStream_t stream);
-hipError_t vkr_launch_cull_deterministic(const CullParams& p, void* state_mem, uint32_t seq, uint32_t resident_blocks, hipStream_t stream);
+hipError_t vkr_launch_cull_deterministic(const CullParams& p, void* state_mem, uint32_t seq, uint32_t resident_blocks, uint32_t* fault, hipStream_t stream);
 
 // The same state as a per-GPU array inside the code object, for the entry point that allocates nothing.
-// vkr_cull_static_init(device) resolves the array's address on `device`, which must be the current device (once
-// per device, at context creation: the first use of a code object on a device may allocate).
-// vkr_cull_static_state returns that address (null before init), the array's size and the sequence number the
-// next call on that device must use; *out_clear_first: the numbers ran out, zero the array before the launch.
+// vkr_cull_static_init(device) resolves the array's address on `device`, which must be the current device, and
+// creates the event that orders the array's users (once per device, at context creation: the first use of a code
+// object on a device may allocate).
+// vkr_launch_cull_static runs the deterministic kernel in that array (hipErrorNotInitialized before init,
+// hipErrorInvalidValue for more than kCullStaticMaxInstances).  All launches on a device share the array, whatever
+// their context: each one is made to wait for the one before (an event recorded behind every launch, waited for
+// in front of the next), so launches from different streams or host threads do not overlap.  On a stream that is
+// being captured into a HIP graph the launch is recorded with the sequence number reserved for recorded launches
+// and a clear of the array in front of it, and takes no part in that ordering: replays that may overlap other
+// users of the array on the same device are the caller's to order.
 constexpr uint64_t kCullStaticMaxInstances = 1ull << 22;
 hipError_t vkr_cull_static_init(int device);
-void* vkr_cull_static_state(int device, uint64_t* out_bytes, uint32_t* out_seq, bool* out_clear_first);
+hipError_t vkr_launch_cull_static(const CullParams& p, int device, uint32_t resident_blocks, uint32_t* fault, hipStream_t stream);
