@@ -131,6 +131,57 @@ def tiled_line(ctx, vkr, synth, frame, K, WU, name, pmc):
     return line, (gbt, outt, lightst, pusht)
 
 
+def configs0_line(ctx, vkr, synth, K, WU, cpu_cores):
+    """The configuration the reference itself runs: a 1920 x 1080 resolve with 32 point lights and a cull of 10 000
+    instances, each timed on the GPU and - cpu_cores > 0 - as the CPU restatement on the whole input (it is small),
+    with every thread of this job's share and with one."""
+    W0, H0, L0, N0, M0 = 1920, 1080, 32, 10_000, 64
+    case = synth.deferred_case(W0, H0, L0, config_index=0)
+    gb = vkr.GBuffer(ctx, W0, H0).upload(case["gbuf"])
+    lights = ctx.buffer_from(case["lights"])
+    out = ctx.image(vkr.FORMAT_R8G8B8A8_UNORM, W0, H0)
+    dargs = vkr.make_deferred_args(gb, out, lights, L0, case["push"])
+    ms = timed(ctx, lambda: ctx.deferred_resolve(dargs), K, WU)
+    by, fl = deferred_algorithmic(W0, H0, L0)
+    res = {"workload": f"{W0}x{H0} resolve with {L0} point lights (rgba8) + frustum cull of {N0} instances in {M0} meshes",
+           "resolve": {"value": W0 * H0 / (ms * 1e-3) / 1e9, "unit": "Gpixel/s", "ms_per_call": ms,
+                       "roofline": {"bound": "valu_fp32", "frac": fl / (ms * 1e-3) / VALU_FP32_PEAK, "hbm_frac": by / (ms * 1e-3) / HBM_PEAK,
+                                    "algorithmic_flops": fl, "algorithmic_bytes": by}}}
+    scene = synth.cull_case(N0, M0, config_index=0)
+    cs = vkr.CullScene(ctx, scene["aabb_min"], scene["aabb_max"], scene["mesh_base"], scene["cmd_template"])
+    res["cull"] = {}
+    for mode_name, flags in (("atomic", 0), ("deterministic", vkr.CULL_DETERMINISTIC)):
+        cargs = cs.args(scene["planes"], flags)
+        cms = timed(ctx, lambda: ctx.prep_indirect(cargs), K, WU)
+        vis = int(cs.results()["cmds"]["instanceCount"].sum())
+        cb = cull_algorithmic(N0, vis, M0)
+        res["cull"][mode_name] = {"value": N0 / (cms * 1e-3) / 1e9, "unit": "G instances/s", "ms_per_call": cms, "visible_fraction": vis / N0,
+                                  "roofline": {"bound": "hbm", "frac": cb / (cms * 1e-3) / HBM_PEAK, "algorithmic_bytes": cb,
+                                               "note": "a launch of ten workgroups: the call is launch latency, not bandwidth"}}
+    if cpu_cores > 0:
+        import oracle  # the CPU baseline: never on the measured GPU path
+        base = {}
+        for name, threads in (("all_cores", cpu_cores), ("one_core", 1)):
+            t0 = time.perf_counter()
+            o = oracle.deferred(case["gbuf"], case["lights"], case["push"], mode="f32", threads=threads, want=("rgba8",))
+            t = time.perf_counter() - t0
+            base[name] = {"value": W0 * H0 / t / 1e9, "unit": "Gpixel/s", "cores": threads, "seconds": t}
+        got = out.download(np.uint8, 4)
+        worst = int(np.abs(got[..., :3].astype(np.int32) - o["rgba8"][..., :3].astype(np.int32)).max())
+        base["kind"], base["sample"] = "port", "the whole frame, binary32 C restatement of deferred.comp"
+        base["max_8bit_difference_from_the_gpu_frame"] = worst
+        res["resolve"]["cpu_baseline"] = base
+        reps = 200  # one cull of 10 000 instances takes the scalar code ~60 us: repeated for a measurable time
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ref = oracle.cull(scene["aabb_min"], scene["aabb_max"], scene["planes"], scene["mesh_base"], scene["cmd_template"], want_mask=False)
+        t = (time.perf_counter() - t0) / reps
+        res["cull"]["cpu_baseline"] = {"value": N0 / t / 1e9, "unit": "G instances/s", "cores": 1, "kind": "port", "seconds_per_call": t,
+                                       "sample": f"all {N0} instances, scalar C restatement, mean of {reps} calls (includes the Python call)",
+                                       "commands_equal_the_gpu's": bool(ref["cmds"].tobytes() == cs.results()["cmds"].tobytes())}
+    return res
+
+
 def bench_callers(ctx, vkr, synth, vdist, args, K, WU, rank, world, barrier, max_over_ranks, band_bench, pmc):
     """The steps before the two passes, each on the headline sizes: per-instance bounds (2^22 instances),
     G-buffer attachment encode and analytic fill (4K), and the 64-frame camera path (cull + fill + resolve
@@ -440,11 +491,39 @@ def main():
             css.append(vkr.CullScene(ctx, sc["aabb_min"], sc["aabb_max"], sc["mesh_base"], sc["cmd_template"]))
         planes = scenes[0]["planes"]
         cull = {}
-        for mode_name, flags in (("atomic", 0), ("deterministic", vkr.CULL_DETERMINISTIC)):
+        for mode_name, flags in (("atomic", 0), ("deterministic", vkr.CULL_DETERMINISTIC), ("atomic_commands_reset_beforehand", vkr.CULL_CMDS_PREZEROED)):
             cargs = [cs.args(planes, flags) for cs in css]
             for i in range(max(WU, nsets)):
                 ctx.prep_indirect(cargs[i % nsets])
             ctx.wait_idle()
+            if flags & vkr.CULL_CMDS_PREZEROED:
+                # the commands of all three sets are reset outside the timed region, as a frame loop resets them behind
+                # its draws; K <= 3 calls per set would be the faithful pattern, so the timed loop runs in rounds of
+                # three calls with the resets of the next round between the timed regions
+                rounds, call_ms_sum = (K + nsets - 1) // nsets, 0.0
+                torch.cuda.synchronize()
+                barrier()
+                c0 = time.perf_counter()
+                for _ in range(rounds):
+                    for a_ in cargs:
+                        ctx.prep_indirect_reset(a_)
+                    e0 = ctx.marker()
+                    for a_ in cargs:
+                        ctx.prep_indirect(a_)
+                    e1 = ctx.marker()
+                    ctx.wait_idle()
+                    call_ms_sum += e1.elapsed_ms_since(e0)
+                torch.cuda.synchronize()
+                barrier()
+                call_ms = call_ms_sum / (rounds * nsets)
+                vis = int(css[0].results()["cmds"]["instanceCount"].sum())
+                cb = cull_algorithmic(N, vis, M)
+                cull[mode_name] = {"ms_per_call": call_ms, "visible_fraction": vis / N, "flag": "VKR_CULL_CMDS_PREZEROED",
+                                   "timed": "the cull launches only (HIP events around each round of three calls); the resets run between the rounds",
+                                   "roofline": {"bound": "hbm", "achieved": cb / (call_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                                "frac": cb / (call_ms * 1e-3) / HBM_PEAK, "traffic": None, "algorithmic_bytes": cb}}
+                assert vis == int(cull["atomic"]["visible_fraction"] * N + 0.5)
+                continue
             torch.cuda.synchronize()
             barrier()
             c0 = time.perf_counter()
@@ -494,15 +573,22 @@ def main():
         result["callers"] = bench_callers(ctx, vkr, synth, vdist, args, K, WU, rank, world, barrier, max_over_ranks, band_bench, pmc if default_workload else {})
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1)
-    if world == 1 and not args.no_cpu_baseline:
+    # Threads of the CPU legs: every CPU this process may run on.  os.cpu_count() reports the whole machine; the
+    # scheduler affinity mask and the thread budget the box exports (OMP_NUM_THREADS) say what this job's share is.
+    host_cpus = os.cpu_count() or 1
+    share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else host_cpus
+    budget = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    cores = max(1, min(share, budget) if budget > 0 else share)
+    cpu_legs = world == 1 and not args.no_cpu_baseline
+    if cpu_legs:
         import oracle  # checker/baseline only: never on the measured GPU path
         oracle.build()
-        # Threads: every CPU this process may run on.  os.cpu_count() reports the whole machine; the scheduler
-        # affinity mask and the thread budget the box exports (OMP_NUM_THREADS) say what this job's share is.
-        host_cpus = os.cpu_count() or 1
-        share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else host_cpus
-        budget = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
-        cores = max(1, min(share, budget) if budget > 0 else share)
+
+    # ---------------------------------------------------------------- the reference's own runnable configuration
+    if rank == 0 and not args.no_cull:
+        result["configs0"] = configs0_line(ctx, vkr, synth, K, WU, cores if cpu_legs else 0)
+
+    if cpu_legs:
         # a bounded sample: about 20 s of CPU work (the scalar restatement shades ~0.18 Mpixel/s per core at 256 lights)
         rows = int(min(H, max(cores, 20.0 * cores * 0.18e6 * (256.0 / max(L, 1)) / W)))
         tc0 = time.perf_counter()

@@ -186,6 +186,14 @@ typedef struct vkr_draw_indexed_indirect_command {
                                      is the form that records); default is one atomic per wave and mesh run (segment
                                      order unspecified) */
 
+#define VKR_CULL_CMDS_PREZEROED 2u /* atomic mode only (ignored with VKR_CULL_DETERMINISTIC, whose launch writes every
+                                     command whole): cmd_out[] already holds what vkr_prep_indirect_reset leaves there,
+                                     so the call skips the launch that would write it (4.6 us of GPU time at 1024
+                                     meshes; calls issued back to back take as long either way, 27.5 us at 2^22
+                                     instances, because that launch runs in the shadow of the previous call's tail).  A
+                                     frame loop resets the commands once its draws have consumed them - behind the
+                                     frame, off the path from camera to commands. */
+
 /* The pass /root/reference/shaders/prep_indirect.comp:1-5 leaves empty.  Instance i carries a
  * world-space AABB and a mesh id; instances of a mesh are contiguous, as the model-matrix array of
  * /root/reference/src/vkmodel.cpp:108-110 is (PerMeshData::modelMatrixBaseIndex,
@@ -220,6 +228,13 @@ typedef struct vkr_cull_args {
  * set, and the next call on this context that waits for the stream - vkr_queue_wait_idle, vkr_buffer_download,
  * vkr_fence_wait, vkr_fence_status when signalled - returns VKR_ERR_DEVICE once, naming the launch. */
 VKR_API int32_t vkr_prep_indirect(vkr_context* ctx, const vkr_cull_args* args);
+
+/* cmd_out[m] = cmd_template[m] with instanceCount = 0 and firstInstance = first_instance + mesh_base[m], for
+ * every mesh: the state vkr_prep_indirect (atomic mode) starts from, and what a frame loop such as
+ * /root/reference/src/main.cpp:198-231 would record after its indirect draws (vkCmdFillBuffer over the counts)
+ * so that the next frame's cull finds its counters at zero.  Only mesh_base, mesh_count, first_instance,
+ * cmd_template and cmd_out of `args` are read. */
+VKR_API int32_t vkr_prep_indirect_reset(vkr_context* ctx, const vkr_cull_args* args);
 
 /* No counterpart in the reference.  For callers that cannot allocate device memory or let a library do it
  * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the deterministic

@@ -49,6 +49,38 @@ def test_parity(vkr, synth, oracle, ctx, n, m, deterministic):
     _compare(res, ref, scene, deterministic)
 
 
+@pytest.mark.parametrize("n,m", [(10000, 1024), (257, 300), (100000, 37), (1 << 20, 512)])
+def test_commands_reset_ahead_of_the_call(vkr, synth, oracle, ctx, n, m):
+    """VKR_CULL_CMDS_PREZEROED: the caller has put the commands into their starting state with
+    vkr_prep_indirect_reset (a frame loop does that behind its draws) and the atomic cull skips its own launch for
+    it.  Three frames with moving planes, each reset -> cull: the oracle's bytes every time; the reset alone leaves
+    the templates with zero counts; the deterministic mode takes the flag and needs no reset."""
+    scene = synth.cull_case(n, m, config_index=n % 13)
+    cs = vkr.CullScene(ctx, scene["aabb_min"], scene["aabb_max"], scene["mesh_base"], scene["cmd_template"])
+    cs.cmd_out.fill_u32(0xDEADBEEF, 0, cs.m * 20 // 4 * 4)
+    ctx.prep_indirect_reset(cs.args(scene["planes"], 0))
+    ctx.wait_idle()
+    start = cs.results()["cmds"]
+    want = scene["cmd_template"].copy()
+    want["instanceCount"] = 0
+    want["firstInstance"] = scene["mesh_base"]
+    assert start.tobytes() == want.tobytes()
+    for frame in range(3):
+        planes = np.asarray(scene["planes"], np.float32).copy()
+        planes[:, 3] += np.float32(3.0 * frame)  # every plane moves outwards: more instances pass
+        ref = oracle.cull(scene["aabb_min"], scene["aabb_max"], planes, scene["mesh_base"], scene["cmd_template"])
+        cs.visible.fill_u32(0xFFFFFFFF)
+        ctx.prep_indirect(cs.args(planes, vkr.CULL_CMDS_PREZEROED))
+        ctx.wait_idle()
+        _compare(cs.results(), ref, scene, False)
+        ctx.prep_indirect_reset(cs.args(planes, 0))  # behind the frame's draws
+    cs.cmd_out.fill_u32(0xDEADBEEF, 0, cs.m * 20 // 4 * 4)
+    cs.visible.fill_u32(0xFFFFFFFF)
+    ctx.prep_indirect(cs.args(scene["planes"], vkr.CULL_DETERMINISTIC | vkr.CULL_CMDS_PREZEROED))
+    ctx.wait_idle()
+    _compare(cs.results(), oracle.cull(scene["aabb_min"], scene["aabb_max"], scene["planes"], scene["mesh_base"], scene["cmd_template"]), scene, True)
+
+
 @pytest.mark.parametrize("deterministic", [False, True])
 def test_golden_fixture(vkr, ctx, deterministic):
     z = np.load(os.path.join(GOLDEN, "cull_4096_M16.npz"))

@@ -31,6 +31,7 @@ DEFERRED_RADIUS_CUTOFF = 1
 DEFERRED_NO_TILE_LISTS = 2
 DEFERRED_WHOLE_TILE_WORKGROUPS = 4
 CULL_DETERMINISTIC = 1
+CULL_CMDS_PREZEROED = 2
 NOALLOC_MAX_INSTANCES = 1 << 22
 LIGHT_STRIDE = 48
 
@@ -157,6 +158,7 @@ EXPORTS = {
     "vkr_deferred_tile_stats": (C.c_int32, [_P, C.POINTER(TileStats)]),
     "vkr_prep_indirect": (C.c_int32, [_P, C.POINTER(CullArgs)]),
     "vkr_prep_indirect_noalloc": (C.c_int32, [_P, C.POINTER(CullArgs)]),
+    "vkr_prep_indirect_reset": (C.c_int32, [_P, C.POINTER(CullArgs)]),
     "vkr_kernel_get": (C.c_int32, [_P, C.c_char_p, _PP]),
     "vkr_kernel_push_constant_size": (C.c_int32, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "vkr_cmd_begin": (C.c_int32, [_P, _PP]),
@@ -452,6 +454,10 @@ class Context:
 
     def prep_indirect(self, args: CullArgs):
         _check(lib().vkr_prep_indirect(self.handle, C.byref(args)))
+
+    def prep_indirect_reset(self, args: CullArgs):
+        """cmd_out := the templates with zero counts: what a cull with CULL_CMDS_PREZEROED starts from."""
+        _check(lib().vkr_prep_indirect_reset(self.handle, C.byref(args)))
 
     def prep_indirect_noalloc(self, args: CullArgs):
         """The deterministic cull with its state in the library's static per-GPU array: no allocation inside the call."""

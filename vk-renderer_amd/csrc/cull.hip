@@ -625,13 +625,19 @@ hipError_t vkr_launch_cull_static(const CullParams& p, int device, uint32_t resi
   return e != hipSuccess ? e : r;
 }
 
-hipError_t vkr_launch_cull_atomic(const CullParams& p, hipStream_t stream) {
+hipError_t vkr_launch_cull_reset(const CullParams& p, hipStream_t stream) {
+  if (p.mesh_count == 0u) return hipSuccess;
+  hipLaunchKernelGGL(cull_init_cmds, dim3((p.mesh_count + 255u) / 256u), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t vkr_launch_cull_atomic(const CullParams& p, bool commands_ready, hipStream_t stream) {
   if (p.mesh_count == 0u) return hipSuccess;
   const uint32_t chunks = (p.instance_count + kAtomicChunk - 1u) / kAtomicChunk;
   // 4 waves per block; cap the grid at 8 blocks per CU and let waves stride over chunks
   uint32_t blocks = (chunks + 3u) / 4u;
   if (blocks > 2048u) blocks = 2048u;
-  hipLaunchKernelGGL(cull_init_cmds, dim3((p.mesh_count + 255u) / 256u), dim3(256), 0, stream, p);
+  if (!commands_ready) hipLaunchKernelGGL(cull_init_cmds, dim3((p.mesh_count + 255u) / 256u), dim3(256), 0, stream, p);
   if (p.instance_count == 0u) return hipGetLastError();
   hipLaunchKernelGGL(cull_atomic_kernel, dim3(blocks), dim3(kBlockThreads), 0, stream, p, chunks);
   return hipGetLastError();

@@ -243,7 +243,7 @@ int32_t run_deferred(vkr_context* ctx, const vkr_deferred_args* a) {
 int32_t run_cull(vkr_context* ctx, const vkr_cull_args* a, bool static_state = false) {
   if (!ctx || !a) return fail(VKR_ERR_INVALID_ARGUMENT, "vkr_prep_indirect: null argument");
   if (a->instance_count >= (1ull << 31)) return fail(VKR_ERR_INVALID_ARGUMENT, "instance_count %llu >= 2^31", (unsigned long long)a->instance_count);
-  if (a->flags & ~VKR_CULL_DETERMINISTIC) return fail(VKR_ERR_INVALID_ARGUMENT, "unknown flags 0x%x", a->flags);
+  if (a->flags & ~(VKR_CULL_DETERMINISTIC | VKR_CULL_CMDS_PREZEROED)) return fail(VKR_ERR_INVALID_ARGUMENT, "unknown flags 0x%x", a->flags);
   static_assert(VKR_NOALLOC_MAX_INSTANCES == kCullStaticMaxInstances, "header limit = kernel limit");
   if (a->mesh_count == 0u) {
     if (a->instance_count != 0u) return fail(VKR_ERR_INVALID_ARGUMENT, "instances without meshes");
@@ -294,7 +294,7 @@ int32_t run_cull(vkr_context* ctx, const vkr_cull_args* a, bool static_state = f
     ctx->cull_seq += 1u;
     VKR_HIP(vkr_launch_cull_deterministic(p, ctx->cull_state, ctx->cull_seq, resident, ctx->cull_fault_device, ctx->stream));
   } else {
-    VKR_HIP(vkr_launch_cull_atomic(p, ctx->stream));
+    VKR_HIP(vkr_launch_cull_atomic(p, (a->flags & VKR_CULL_CMDS_PREZEROED) != 0u, ctx->stream));
   }
   return VKR_OK;
 }
@@ -624,6 +624,20 @@ int32_t vkr_deferred_tile_stats(vkr_context* ctx, vkr_tile_stats* out) {
   return VKR_OK;
 }
 int32_t vkr_prep_indirect(vkr_context* ctx, const vkr_cull_args* args) { return run_cull(ctx, args); }
+int32_t vkr_prep_indirect_reset(vkr_context* ctx, const vkr_cull_args* a) {
+  if (!ctx || !a) return fail(VKR_ERR_INVALID_ARGUMENT, "vkr_prep_indirect_reset: null argument");
+  if (a->mesh_count == 0u) return VKR_OK;
+  if (!a->mesh_base || !a->cmd_template || !a->cmd_out) return fail(VKR_ERR_INVALID_ARGUMENT, "mesh_base / cmd_template / cmd_out: null");
+  CullParams p{};
+  p.mesh_base = a->mesh_base;
+  p.cmd_template = reinterpret_cast<const DrawCmd*>(a->cmd_template);
+  p.cmd_out = reinterpret_cast<DrawCmd*>(a->cmd_out);
+  p.mesh_count = a->mesh_count;
+  p.first_instance = a->first_instance;
+  VKR_HIP(hipSetDevice(ctx->device));
+  VKR_HIP(vkr_launch_cull_reset(p, ctx->stream));
+  return VKR_OK;
+}
 int32_t vkr_prep_indirect_noalloc(vkr_context* ctx, const vkr_cull_args* args) {
   if (!ctx || !args) return fail(VKR_ERR_INVALID_ARGUMENT, "vkr_prep_indirect_noalloc: null argument");
   if (args->instance_count > VKR_NOALLOC_MAX_INSTANCES)

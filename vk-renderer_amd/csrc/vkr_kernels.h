@@ -130,7 +130,9 @@ constexpr uint32_t kCullSeqEnd = 1u << 30;
 constexpr uint32_t kCullSeqRecorded = kCullSeqEnd - 1u;
 uint64_t vkr_cull_state_bytes(uint64_t instance_count);
 uint32_t vkr_cull_blocks_per_cu();
-hipError_t vkr_launch_cull_atomic(const CullParams& p, hipStream_t stream);
+// commands_ready: cmd_out already holds the templates with zero counts (vkr_launch_cull_reset), skip that launch
+hipError_t vkr_launch_cull_atomic(const CullParams& p, bool commands_ready, hipStream_t stream);
+hipError_t vkr_launch_cull_reset(const CullParams& p, hipStream_t stream);
 hipError_t vkr_launch_cull_deterministic(const CullParams& p, void* state_mem, uint32_t seq, uint32_t resident_blocks, uint32_t* fault, hipStream_t stream);
 
 // The same state as a per-GPU array inside the code object, for the entry point that allocates nothing.
