@@ -303,6 +303,7 @@ def main():
     ap.add_argument("--no-cull", action="store_true")
     ap.add_argument("--no-cold", action="store_true", help="skip the run that rotates over four G-buffer sets")
     ap.add_argument("--only-tiled", choices=sorted(TILED_WORKLOADS), help="run this radius-cutoff workload and nothing else (counter passes: the list kernels' per-launch averages then belong to one workload)")
+    ap.add_argument("--no-configs0", action="store_true", help="skip the 1080p x 32 + 10k-instance configuration (counter passes: its launches would enter the per-kernel averages of the headline sizes)")
     ap.add_argument("--no-callers", action="store_true", help="skip the steps either side of the passes (bounds, G-buffer producers, camera path)")
     args = ap.parse_args()
 
@@ -585,7 +586,7 @@ def main():
         oracle.build()
 
     # ---------------------------------------------------------------- the reference's own runnable configuration
-    if rank == 0 and not args.no_cull:
+    if rank == 0 and not args.no_cull and not args.no_configs0:
         result["configs0"] = configs0_line(ctx, vkr, synth, K, WU, cores if cpu_legs else 0)
 
     if cpu_legs:

@@ -38,6 +38,32 @@ if os.path.isdir(os.path.join(src, "trace_headline")):  # the headline part alon
     if line:
         open(os.path.join(dst, f"{tag}_bench_headline_under_trace.json"), "w").write(line[-1])
 
+def headline_launches():
+    """The headline kernel's launches in the trace of `bench.py --no-callers --no-cpu-baseline`, in start order: W
+    warm-up launches, K timed ones (the bench line's kernel_ms is the HIP-event mean of exactly those), then the
+    run over four rotating G-buffer sets.  The stats file's average is over all of them, cold-clock launches
+    included; the mean of the K timed launches is the one to hold against the bench line."""
+    line_path = os.path.join(dst, f"{tag}_bench_headline_under_trace.json")
+    trace = glob.glob(os.path.join(src, "trace_headline", "*", "*kernel_trace.csv"))
+    if not trace or not os.path.exists(line_path):
+        return
+    line = json.load(open(line_path))
+    rows = [r for r in csv.DictReader(open(max(trace, key=os.path.getmtime))) if "deferred_kernel<0, false, 4>" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
+    w, k = line["warmup"], line["steps"]
+    timed = dur[w:w + k]
+    res = {"kernel": "deferred_kernel<0, false, 4>", "launches_in_trace": len(dur), "mean_all_launches_ms": sum(dur) / len(dur) / 1e6,
+           "timed_steps": {"launches": len(timed), "mean_ms": sum(timed) / len(timed) / 1e6, "median_ms": sorted(timed)[len(timed) // 2] / 1e6, "min_ms": min(timed) / 1e6},
+           "warmup_launches_ms": [d / 1e6 for d in dur[:w]],
+           "bench_line_kernel_ms": line["roofline"]["kernel_ms"], "bench_line_kernel_ms_median": line["roofline"]["kernel_ms_median"]}
+    res["timed_mean_over_bench_kernel_ms"] = res["timed_steps"]["mean_ms"] / res["bench_line_kernel_ms"]
+    json.dump(res, open(os.path.join(dst, f"{tag}_headline_kernel.json"), "w"), indent=1)
+    print("headline kernel:", res["timed_steps"], "bench line:", res["bench_line_kernel_ms"])
+
+
+headline_launches()
+
 out = collections.defaultdict(dict)
 for f in [newest(os.path.join(d, "*", "*counter_collection.csv")) for d in glob.glob(os.path.join(src, "pmc_*")) if os.path.isdir(d)]:
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
