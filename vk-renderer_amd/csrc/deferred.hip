@@ -1249,7 +1249,7 @@ __global__ __launch_bounds__(kDeep ? 256 : 64, 4) void deferred_list_kernel(cons
 // (deferred.comp:107) - 12 bytes per pixel instead of 24, and the shading kernel never sees the tile.  The other
 // tiles are queued for deferred_list_kernel.
 template <int kOutMode>
-__global__ __launch_bounds__(256) void tile_lists_kernel(const DeferredParams p, const TileListOut o) {
+__global__ __launch_bounds__(256, 5) void tile_lists_kernel(const DeferredParams p, const TileListOut o) {
   __shared__ uint32_t s_lit[4], s_class[4];
   __shared__ uint32_t s_cell[4][64];  // per wave: pixels per depth cell, then where each cell's pixels begin
   __shared__ uint32_t s_range[4][16];  // per wave: depth range (bit patterns) of each of the eight groups of a deep tile
@@ -1260,6 +1260,13 @@ __global__ __launch_bounds__(256) void tile_lists_kernel(const DeferredParams p,
   if (blockIdx.x == 0u && t < kListCounterStride) o.counters_next[t] = 0u;  // the counters of the launch after this one
   uint32_t lit_tile = 0xFFFFFFFFu, lit_class = 0u;
   bool qualifies = false;  // as a deep tile (wave-uniform)
+#ifdef VKR_X_TIMES  // measurement builds only (tools/tile_phase_times.py): the wall clock at the end of each phase of a tile's wave
+  unsigned long long stamp[8] = {};
+#define VKR_STAMP(i) stamp[i] = wall_clock64()
+  VKR_STAMP(0);
+#else
+#define VKR_STAMP(i)
+#endif
   if (tile < n_tiles) {  // wave-uniform
     const uint32_t tile_y = tile / p.tiles_x, tile_x = tile - tile_y * p.tiles_x;
     const uint32_t x0 = tile_x * 32u + (lane & 7u) * 4u;
@@ -1288,7 +1295,9 @@ __global__ __launch_bounds__(256) void tile_lists_kernel(const DeferredParams p,
       dmin = fminf(dmin, __shfl_xor(dmin, off));
       dmax = fmaxf(dmax, __shfl_xor(dmax, off));
     }
+    VKR_STAMP(1);  // depth arrived, range known
     const TileBounds b = tile_bounds(p, tile_x, tile_y, dmin, dmax, lane);
+    VKR_STAMP(2);  // bounds
 
     const float4* __restrict__ lights = reinterpret_cast<const float4*>(p.lights);
     const uint32_t L = p.light_count;
@@ -1331,6 +1340,7 @@ __global__ __launch_bounds__(256) void tile_lists_kernel(const DeferredParams p,
         count += (uint32_t)__popcll(hits);
       }
     }
+    VKR_STAMP(3);  // the tile's list
     bool deep = false;  // wave-uniform
     if (count != 0u) {
       // A tile whose pixels span more depth than a light reaches (an object's edge in front of a far background, or
@@ -1379,6 +1389,7 @@ __global__ __launch_bounds__(256) void tile_lists_kernel(const DeferredParams p,
               order[s_cell[wv][rank[k][i] >> 16] + (rank[k][i] & 0xFFFFu)] = (uint16_t)((((lane >> 3) + 8u * k) << 5) | ((lane & 7u) * 4u + (uint32_t)i));
           }
         }
+        VKR_STAMP(4);  // pixel order written
         // Depth range of each group of 128 consecutive pixels of that order (depths are not negative: their bit
         // patterns order like the numbers), then the group's own bounds - the tile's extent on screen, the group's in
         // depth - and the part of the tile's list that can reach them, in list order.
@@ -1446,6 +1457,7 @@ __global__ __launch_bounds__(256) void tile_lists_kernel(const DeferredParams p,
             ghi[a] = ok ? ghi[a] + pad : INFINITY;
           }
         }
+        VKR_STAMP(5);  // group ranges and boxes
         const uint32_t tile_pixels = min(32u, p.width - tile_x * 32u) * min(32u, p.height - tile_y * 32u);
         const uint32_t groups = (tile_pixels + 127u) / 128u;
         uint32_t kept[8] = {};  // wave-uniform
@@ -1509,6 +1521,7 @@ __global__ __launch_bounds__(256) void tile_lists_kernel(const DeferredParams p,
       }
     }
     if (lane == 0u) o.tile_count[tile] = count > p.list_cap ? (count | kTileOverflow) : (deep ? (count | kTileDeep) : count);
+    VKR_STAMP(6);  // group lists (or the dark tile's pixels) written
   }
   if (lane == 0u) {
     s_lit[wv] = lit_tile;
@@ -1533,6 +1546,13 @@ __global__ __launch_bounds__(256) void tile_lists_kernel(const DeferredParams p,
         if (s_lit[w] != 0xFFFFFFFFu && (s_class[w] & 0xFFu) == t) queue[slot++] = s_lit[w];
     }
   }
+#ifdef VKR_X_TIMES
+  if (lane == 0u && tile < n_tiles && tile < 32768u) {
+    VKR_STAMP(7);  // queue push
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g_wave_times[8u * tile + i] = stamp[i];
+  }
+#endif
 }
 
 // Device self-check of exact_div against the compiler's IEEE division over the operand ranges the
