@@ -339,7 +339,7 @@ def test_resolve_kernels_use_no_scratch_memory():
     for name, k in kernels.items():
         flat = re.search(r"deferred_kernelILi(\d)ELb([01])ELi(\d)EE", name)
         pixel = re.search(r"deferred_pixel_kernelILi(\d)ELb([01])EE", name)
-        production = (flat and flat.group(2) == "0") or (pixel and pixel.group(2) == "0") or "deferred_list_kernel" in name or "tile_lists_kernel" in name or "light_bins_kernel" in name
+        production = (flat and flat.group(2) == "0") or (pixel and pixel.group(2) == "0") or "deferred_list_kernel" in name or "deferred_deep_kernel" in name or "tile_lists_kernel" in name or "light_bins_kernel" in name
         if not production:
             continue  # the whole-table loop with the per-pixel cutoff is a diagnostic, not a production path
         assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0, (name, k)

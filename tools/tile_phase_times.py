@@ -22,8 +22,20 @@ def main():
     lib = vkr.lib()
     lib.vkr_x_wave_times.argtypes = [C.c_void_p, C.c_uint]
     name = sys.argv[1] if len(sys.argv) > 1 else "tiled_resolve_8k_discontinuous"
+    deep = len(sys.argv) > 2 and sys.argv[2] == "deep"  # library built with -DVKR_X_TIMES=2: the deep-tile workgroups instead
     ctx = vkr.Context(0)
     line, keep = bench.tiled_line(ctx, vkr, synth, frame, 6, 3, name, {})
+    if deep:
+        buf = np.zeros((8192 * 8, 4), np.uint64)
+        assert lib.vkr_x_wave_times(buf.ctypes.data_as(C.c_void_p), 8192 * 8) == 0
+        st = buf.reshape(8192, 4, 8).astype(np.int64)
+        st = st[st[:, 0, 0] != 0]  # tiles below 8192 that were deep
+        names = ("requests issued", "barrier: planes in LDS", "first group shaded", "second group shaded", "barrier: all groups done", "rows stored + barrier")
+        d = np.diff(st[:, :, :7], axis=2) / 100.0
+        print(json.dumps({"workload": name, "ms_per_call": line["ms_per_call"], "deep_tiles_sampled": int(st.shape[0]),
+                          "workgroup_time_per_tile_us": float((st[:, 0, 6] - st[:, 0, 0]).mean() / 100.0),
+                          "phase_mean_us_by_wave": {names[i]: [float(d[:, w, i].mean()) for w in range(4)] for i in range(6)}}, indent=1))
+        return
     tiles = min(line["lists"]["tiles"], 32768)
     buf = np.zeros((tiles * 2, 4), np.uint64)
     assert lib.vkr_x_wave_times(buf.ctypes.data_as(C.c_void_p), tiles * 2) == 0

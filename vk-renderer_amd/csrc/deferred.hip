@@ -928,24 +928,12 @@ constexpr uint32_t kStripRows = 4, kStripsPerTile = 32 / kStripRows, kWaveChunk 
 constexpr uint32_t kDeepMinList = VKR_X_DEEP_MIN;  // shorter lists are walked whole: narrowing them costs more than it saves
 constexpr float kDeepSpanRadii = 1.0f;    // a tile is deep when its near and far ends are further apart than this many radii
 
-// kDeep = false: single-wave workgroups over the strips of the tiles in the four list-class queues, as described above.
-// kDeep = true : the tiles that tile_lists_kernel marked deep (more depth than a light reaches).  A workgroup of
-// four waves takes one such tile: the tile's four planes go through LDS (read from memory once, in whole rows), wave w
-// shades groups w and w + 4 of the tile's depth order - 128 pixels of similar depth each, wherever they lie in the
-// tile - from the groups' own lists, and the 8-bit result leaves through LDS again, in whole rows.  (With the groups' pixels fetched
-// straight from memory, every wave touched nearly every cache line of the tile: eight times the traffic, in 4-byte
-// pieces - 1.2 ms for the 8K frame whose depth is uncorrelated between neighbours.)
-template <int kOutMode, bool kDeep>
-__global__ __launch_bounds__(kDeep ? 256 : 64, 4) void deferred_list_kernel(const DeferredParams p) {
-  constexpr uint32_t kWaves = kDeep ? 4u : 1u, kTilePixels = kDeep ? 1024u : 1u;
-  __shared__ float4 s_light_of[kWaves][2 * kWaveChunk + 4];  // +1 pair: the prefetch of the last iteration reads past the list
-  __shared__ uint32_t s_keep_of[kDeep ? 1 : 4][64];           // strips: albedo and material words, waiting for the end of the loop
-  __shared__ uint32_t s_alb[kTilePixels], s_mat[kTilePixels], s_out[kTilePixels];  // deep: the tile's planes, texel y * 32 + x
-  __shared__ float s_dep[kTilePixels];
-  __shared__ uint2 s_nrm[kTilePixels];
+template <int kOutMode>
+__global__ __launch_bounds__(64, 4) void deferred_list_kernel(const DeferredParams p) {
+  __shared__ float4 s_light[2 * kWaveChunk + 4];  // +1 pair: the prefetch of the last iteration reads past the list
+  __shared__ uint32_t s_keep[4][64];              // albedo and material words, waiting for the end of the loop
   constexpr bool kIs8Bit = kOutMode == kOutRgba8 || kOutMode == kOutBgra8;
-  const uint32_t t = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // lane, wave of the workgroup (the same in every lane)
-  float4* const s_light = s_light_of[wv];
+  const uint32_t t = threadIdx.x;
   const float4* __restrict__ lights = reinterpret_cast<const float4*>(p.lights);
   const uint32_t L = p.light_count;
   LoopConsts kc;
@@ -964,54 +952,21 @@ __global__ __launch_bounds__(kDeep ? 256 : 64, 4) void deferred_list_kernel(cons
     }
   }
   const uint32_t n_tiles = p.tiles_x * p.tiles_y;
-  const uint32_t q_end = kDeep ? p.lit_counters[kListClasses] : kStripsPerTile * class_end[kListClasses - 1];
+  const uint32_t q_end = kStripsPerTile * class_end[kListClasses - 1];
   // for the host's next call: how many tiles of this frame qualify as deep (a store to host memory, nobody waits for it)
-  if (!kDeep && blockIdx.x == 0u && threadIdx.x == 0u && p.deep_hint) __hip_atomic_store(p.deep_hint, p.lit_counters[kDeepCounter], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (blockIdx.x == 0u && threadIdx.x == 0u && p.deep_hint) __hip_atomic_store(p.deep_hint, p.lit_counters[kDeepCounter], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #pragma unroll 1
   for (uint32_t q = blockIdx.x; q < q_end; q += gridDim.x) {
-    uint32_t tile, strip;
-    if (kDeep) {
-      tile = p.lit_queue[(size_t)kListClasses * n_tiles + q];
-      strip = wv;  // the first of the two groups of the tile's depth order this wave shades
-    } else {
-      const uint32_t pos = q / kStripsPerTile;
-      strip = q % kStripsPerTile;
-      uint32_t cls = kListClasses - 1u, first = 0u;  // position of the concatenated queues -> (class, index)
+    const uint32_t pos = q / kStripsPerTile, strip = q % kStripsPerTile;
+    uint32_t cls = kListClasses - 1u, first = 0u;  // position of the concatenated queues -> (class, index)
 #pragma unroll
-      for (uint32_t k = 0; k + 1u < kListClasses; ++k)
-        if (pos >= class_end[k]) cls = kListClasses - 2u - k, first = class_end[k];
-      tile = p.lit_queue[(size_t)cls * n_tiles + (pos - first)];
-    }
+    for (uint32_t k = 0; k + 1u < kListClasses; ++k)
+      if (pos >= class_end[k]) cls = kListClasses - 2u - k, first = class_end[k];
+    const uint32_t tile = p.lit_queue[(size_t)cls * n_tiles + (pos - first)];
     const uint32_t tile_y = tile / p.tiles_x, tile_x = tile - tile_y * p.tiles_x;
     const uint32_t word = p.tile_count[tile];
-    if (kDeep) {
-      // the tile's planes, 16 bytes per thread and request (rows hold whole 4-texel groups): 256 requests each for albedo,
-      // material and depth, 512 for the normals
-      {
-        uint32_t c = threadIdx.x;
-        asm volatile("" : "+v"(c));  // addresses derived per tile, not kept from the kernel's entry across the light loop
-        const uint32_t r = c >> 3, x4 = (c & 7u) * 4u;
-        const uint32_t gx = tile_x * 32u + x4, gy = tile_y * 32u + r;
-        if (gx < p.width && gy < p.height) {
-          *reinterpret_cast<uint4*>(s_alb + r * 32u + x4) = *reinterpret_cast<const uint4*>(p.albedo + (size_t)gy * p.pitch_albedo + (size_t)gx * 4u);
-          *reinterpret_cast<uint4*>(s_mat + r * 32u + x4) = *reinterpret_cast<const uint4*>(p.material + (size_t)gy * p.pitch_material + (size_t)gx * 4u);
-          *reinterpret_cast<float4*>(s_dep + r * 32u + x4) = *reinterpret_cast<const float4*>(p.depth + (size_t)gy * p.pitch_depth + (size_t)gx * 4u);
-        }
-#pragma unroll
-        for (uint32_t h = 0; h < 2u; ++h) {  // two 8-byte texels per request
-          const uint32_t c2 = c + 256u * h, r2 = c2 >> 4, x2 = (c2 & 15u) * 2u;
-          const uint32_t hx = tile_x * 32u + x2, hy = tile_y * 32u + r2;
-          if (hx < p.width && hy < p.height)
-            *reinterpret_cast<uint4*>(s_nrm + r2 * 32u + x2) = *reinterpret_cast<const uint4*>(p.normal + (size_t)hy * p.pitch_normal + (size_t)hx * 8u);
-        }
-      }
-      __syncthreads();
-    }
-#pragma unroll 1
-    for (uint32_t pass = 0; pass < (kDeep ? 2u : 1u); ++pass) {  // a deep tile's wave shades two groups, one after the other
-    if (kDeep) strip = wv + 4u * pass;
     uint32_t count = L;                           // lights this unit walks
-    const uint16_t* __restrict__ tl = nullptr;    // the tile's (or the group's) own list, or
+    const uint16_t* __restrict__ tl = nullptr;    // the tile's own list, or
     const uint32_t* __restrict__ cand = nullptr;  // its bin's candidates when the list overflowed
     if (word & kTileOverflow) {
       if (p.bin_list) {
@@ -1023,218 +978,366 @@ __global__ __launch_bounds__(kDeep ? 256 : 64, 4) void deferred_list_kernel(cons
       tl = p.tile_list + (size_t)tile * p.list_cap;
       count = word & kTileCountMask;
     }
-    bool active = true;  // wave-uniform; only a deep tile's workgroup keeps waves without work (they meet the barriers)
-    if (kDeep) {
-      const uint32_t tile_pixels = min(32u, p.width - tile_x * 32u) * min(32u, p.height - tile_y * 32u);
-      active = strip * 128u < tile_pixels;  // a tile at the image's edge has fewer groups
-      // the group's own list: the part of the tile's list that can reach the group's depth range (tile_lists_kernel)
-      const uint32_t own = active ? p.group_count[(size_t)tile * kStripsPerTile + strip] : 0u;
-      if (own != kGroupOverflow) {
-        tl = p.group_list + ((size_t)tile * kStripsPerTile + strip) * kGroupListCap;
-        count = own;
-      }
-    }
-    // Where the lane's two pixels a and b are: derived from the thread index where needed (through a copy the compiler
-    // cannot see through) rather than kept across the light loop, which leaves no register for values that wait.
-    // A strip's lane has two neighbouring pixels of a row; a deep tile's lane has entries 2l and 2l+1 of its group in
-    // the tile's depth order (ida, idb: y * 32 + x within the tile).  A pixel that does not exist (beyond the image,
-    // or beyond the tile's last pixel) is replaced by one that does and not stored.
+    // Where the lane's two pixels are (neighbours in a row): derived from the thread index where needed (through a copy
+    // the compiler cannot see through) rather than kept across the light loop, which leaves no register for values that
+    // wait.  A pair beyond the image is replaced by the tile's first (in bounds by construction) and not stored.
     struct Where {
-      uint32_t xa, ya, xb, yb, ida, idb;
-      bool ina, inb;
+      uint32_t x0, y, lx, ly;
+      bool inside;
     };
     auto where = [&](uint32_t tq) {
       uint32_t ox = tile_x * 32u, oy = tile_y * 32u, oys = tile_y * 32u + strip * kStripRows;
       asm volatile("" : "+v"(tq), "+s"(ox), "+s"(oy), "+s"(oys));
       Where w;
-      if (!kDeep) {
-        const uint32_t x0 = ox + (tq & 15u) * 2u, y = oys + (tq >> 4);
-        const bool inside = (x0 < p.width) && (y < p.height);
-        w.xa = inside ? x0 : ox;
-        w.ya = w.yb = inside ? y : oy;
-        w.xb = w.xa + 1u;  // may lie in the row's padding: read, never stored
-        w.ina = inside;
-        w.inb = inside && x0 + 1u < p.width;
-        w.ida = w.idb = 0u;
-      } else {
-        const uint32_t tile_pixels = min(32u, p.width - ox) * min(32u, p.height - oy);
-        const uint32_t j = strip * 128u + 2u * tq;
-        w.ina = j < tile_pixels;
-        w.inb = j + 1u < tile_pixels;
-        const uint32_t pair = reinterpret_cast<const uint32_t*>(p.tile_order + (size_t)tile * 1024u)[(w.ina ? j : strip * 128u) >> 1];
-        w.ida = pair & 0xFFFFu;
-        w.idb = w.inb ? pair >> 16 : w.ida;
-        w.xa = ox + (w.ida & 31u);
-        w.ya = oy + (w.ida >> 5);
-        w.xb = ox + (w.idb & 31u);
-        w.yb = oy + (w.idb >> 5);
-      }
+      w.x0 = ox + (tq & 15u) * 2u;
+      w.y = oys + (tq >> 4);
+      w.inside = (w.x0 < p.width) && (w.y < p.height);
+      w.lx = w.inside ? w.x0 : ox;
+      w.ly = w.inside ? w.y : oy;
       return w;
     };
-    if (active) {
-      const Where w0 = where(t);
-      if (!kDeep && __ballot(w0.ina) == 0ull) continue;  // a strip below the image's last row (wave-uniform)
-      uint2 alb2, mat2;
-      float2 dep2;
-      uint4 nrm;
-      if (!kDeep) {
-        alb2 = *reinterpret_cast<const uint2*>(p.albedo + (size_t)w0.ya * p.pitch_albedo + (size_t)w0.xa * 4u);
-        mat2 = *reinterpret_cast<const uint2*>(p.material + (size_t)w0.ya * p.pitch_material + (size_t)w0.xa * 4u);
-        dep2 = *reinterpret_cast<const float2*>(p.depth + (size_t)w0.ya * p.pitch_depth + (size_t)w0.xa * 4u);
-        nrm = *reinterpret_cast<const uint4*>(p.normal + (size_t)w0.ya * p.pitch_normal + (size_t)w0.xa * 8u);
-      } else {
-        alb2 = make_uint2(s_alb[w0.ida], s_alb[w0.idb]);
-        mat2 = make_uint2(s_mat[w0.ida], s_mat[w0.idb]);
-        dep2 = make_float2(s_dep[w0.ida], s_dep[w0.idb]);
-        const uint2 na = s_nrm[w0.ida], nb = s_nrm[w0.idb];
-        nrm = make_uint4(na.x, na.y, nb.x, nb.y);
+    const Where w0 = where(t);
+    if (__ballot(w0.inside) == 0ull) continue;  // a strip below the image's last row (wave-uniform)
+    const uint2 alb2 = *reinterpret_cast<const uint2*>(p.albedo + (size_t)w0.ly * p.pitch_albedo + (size_t)w0.lx * 4u);
+    const uint2 mat2 = *reinterpret_cast<const uint2*>(p.material + (size_t)w0.ly * p.pitch_material + (size_t)w0.lx * 4u);
+    const float2 dep2 = *reinterpret_cast<const float2*>(p.depth + (size_t)w0.ly * p.pitch_depth + (size_t)w0.lx * 4u);
+    const uint4 nrm = *reinterpret_cast<const uint4*>(p.normal + (size_t)w0.ly * p.pitch_normal + (size_t)w0.lx * 8u);
+    const float4 black_pos = make_float4(0.0f, 0.0f, 1e18f, 0.0f), black_col = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    // A chunk of the list is one index, then one record, per lane.  The first chunk's records are requested here,
+    // alongside the planes; of a later chunk only the index is requested ahead (one register across the light loop
+    // where the record would take eight), the record when the chunk's turn comes.
+    auto fetch_index = [&](uint32_t base) -> uint32_t {
+      uint32_t tq = t;
+      asm volatile("" : "+v"(tq));  // the addresses below are derived per call, not kept in registers across the light loop
+      const uint32_t j = min(base + tq, count - 1u);
+      return tl ? (uint32_t)tl[j] : (cand ? cand[j] : j);
+    };
+    auto fetch_records = [&](uint32_t base, uint32_t idx, float4& lp, float4& lc) {
+      lp = black_pos;
+      lc = black_col;
+      if (base + t < count) {
+        lp = lights[3u * idx];       // pos.xyz, opening_angle (unused)
+        lc = lights[3u * idx + 1u];  // color.xyz, penumbra_angle (unused)
       }
-      const float4 black_pos = make_float4(0.0f, 0.0f, 1e18f, 0.0f), black_col = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      // A chunk of the list is one index, then one record, per lane.  The first chunk's records are requested here,
-      // alongside the planes; of a later chunk only the index is requested ahead (one register across the light loop
-      // where the record would take eight), the record when the chunk's turn comes.
-      auto fetch_index = [&](uint32_t base) -> uint32_t {
-        uint32_t tq = t;
-        asm volatile("" : "+v"(tq));  // the addresses below are derived per call, not kept in registers across the light loop
-        const uint32_t j = min(base + tq, count - 1u);
-        return tl ? (uint32_t)tl[j] : (cand ? cand[j] : j);
+    };
+    float4 lp = black_pos, lc = black_col;
+    if (count != 0u) fetch_records(0u, fetch_index(0u), lp, lc);
+    uint32_t width = p.width, full_height = p.full_height;
+    asm volatile("" : "+s"(width), "+s"(full_height));  // their reciprocals are derived per unit, not kept in vector registers
+    const ExactRcp by_width = exact_rcp((float)width), by_height = exact_rcp((float)full_height);
+    const float cy = clip_coord(w0.ly + p.row_offset, by_height);
+    Pixel s[2];
+    setup_pixel(s[0], p, clip_coord(w0.lx, by_width), cy, dep2.x, mat2.x, nrm.x, nrm.y);
+    setup_pixel(s[1], p, clip_coord(w0.lx + 1u, by_width), cy, dep2.y, mat2.y, nrm.z, nrm.w);
+    // the albedo and material words are decoded after the loop: they wait in LDS, one column per lane
+    s_keep[0][t] = alb2.x;
+    s_keep[1][t] = alb2.y;
+    s_keep[2][t] = mat2.x;
+    s_keep[3][t] = mat2.y;
+
+    uint32_t probe_left = kProbeBudget;
+    // a wave whose pixels all have a v.n that is a number <= 1e-6 gets 0 from every light (deferred.comp:43,84) and
+    // does not need to know whether one lay in range: it keeps its ambient colour either way
+    if (__ballot(!(s[0].vn <= kEarlyOut) || !(s[1].vn <= kEarlyOut)) == 0ull) {
+      VKR_COUNT_TRIPS((count + 1u) / 2u, 0u, (count + 1u) / 2u);
+      count = 0u;
+    }
+    uint32_t next_idx = 0;
+    for (uint32_t base = 0; base < count; base += kWaveChunk) {
+      const uint32_t n = min(kWaveChunk, count - base);
+      const uint32_t n2 = (n + 1u) & ~1u;
+      // one wave: its LDS accesses execute in program order, no barrier is needed between the loop's reads of
+      // the previous chunk and these writes
+      if (base != 0u) fetch_records(base, next_idx, lp, lc);
+      s_light[2u * t] = lp;
+      s_light[2u * t + 1u] = lc;
+      Probe probe{probe_budget_for(n2 / 2u, probe_left)};
+      if (base + kWaveChunk < count) next_idx = fetch_index(base + kWaveChunk);  // the next chunk's indices, while this one is shaded
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const float4* rec = s_light;
+      float4 pa = rec[0], ca = rec[1], pb = rec[2], cb = rec[3];
+      uint32_t j = 0;
+      for (; j < n2 && probe.budget != 0u; j += 2u) {  // see deferred_kernel: the loop with the test, then the one without
+        const Light AB[2] = {{pa.x, pa.y, pa.z, ca.x, ca.y, ca.z}, {pb.x, pb.y, pb.z, cb.x, cb.y, cb.z}};
+        rec += 4;  // next pair (one pair beyond the list on the last trip: read, never used)
+        shade4<true, true>(
+            s[0], s[1], AB, kc, probe, [&] { pa = rec[0], pb = rec[2]; }, [&] { ca = rec[1], cb = rec[3]; });
+      }
+      if (j < n2) {
+        const float4* rec2 = s_light + 2u * j;
+        float4 pa2 = rec2[0], ca2 = rec2[1], pb2 = rec2[2], cb2 = rec2[3];
+        for (; j < n2; j += 2u) {
+          const Light AB[2] = {{pa2.x, pa2.y, pa2.z, ca2.x, ca2.y, ca2.z}, {pb2.x, pb2.y, pb2.z, cb2.x, cb2.y, cb2.z}};
+          rec2 += 4;
+          pa2 = rec2[0];
+          ca2 = rec2[1];
+          pb2 = rec2[2];
+          cb2 = rec2[3];
+          shade4<true, false>(s[0], s[1], AB, kc, probe, [] {}, [] {});
+        }
+      }
+      probe_left = probe.budget;
+#ifdef VKR_X_COUNT
+      VKR_COUNT_TRIPS(n2 / 2u, probe.skipped, 0u);
+#endif
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    float rgb[2][3];
+    finish_pixel(s[0], s_keep[0][t], s_keep[2][t], s[0].in_range > 0.0f, rgb[0]);
+    finish_pixel(s[1], s_keep[1][t], s_keep[3][t], s[1].in_range > 0.0f, rgb[1]);
+    const Where w1 = where(t);
+    if (w1.inside) {
+      const uint32_t x0 = w1.x0, y = w1.y;
+      const bool both = x0 + 1u < p.width;
+      uint8_t* orow = p.out + (size_t)y * p.pitch_out;
+      if (kIs8Bit) {
+        uint32_t* o = reinterpret_cast<uint32_t*>(orow) + x0;
+        const uint32_t t0 = pack_unorm8<kOutMode>(rgb[0]), t1 = pack_unorm8<kOutMode>(rgb[1]);
+        if (both)
+          *reinterpret_cast<uint2*>(o) = make_uint2(t0, t1);
+        else
+          o[0] = t0;
+      } else if (kOutMode == kOutRgba16f) {
+        uint2* o = reinterpret_cast<uint2*>(orow) + x0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          if (i == 0 || both) o[i] = half_texel(rgb[i][0], rgb[i][1], rgb[i][2]);
+        }
+      } else {
+        float4* o = reinterpret_cast<float4*>(orow) + x0;
+        o[0] = make_float4(rgb[0][0], rgb[0][1], rgb[0][2], 1.0f);
+        if (both) o[1] = make_float4(rgb[1][0], rgb[1][1], rgb[1][2], 1.0f);
+      }
+    }
+  }
+}
+
+// The tiles that tile_lists_kernel marked deep (more depth than a light reaches).  A workgroup of four waves takes one
+// such tile.  The tile's four planes go through LDS (read from memory once, in whole rows); the tile's pixels, in the
+// depth order tile_lists_kernel wrote, form 16 units of 64 - one pixel per lane, wherever it lies in the tile - and
+// units 2g and 2g + 1 walk the list of depth group g, four lights per trip (the same four evaluations per trip, and
+// per pixel the same sums in the same order, as everywhere else).  The waves take the units one at a time, the
+// farthest first: clip-space depth crowds the far distances together, so the last groups of the depth order span the
+// most space and keep the longest lists (uncorrelated depth at 8K x 4096: 22 lights and more against 1-3) - begun
+// first, they end with the rest.  The 8-bit result leaves through LDS again, in whole rows.
+// Measured on the way (8K x 4096, depth uncorrelated between neighbours, this kernel alone): pixels fetched straight
+// from memory in depth order, no LDS: 1.2 ms (every wave touches nearly every cache line of the tile, in 4-byte
+// pieces); planes through LDS, wave w shading groups w and w + 4 as pairs of pixels: 0.53 ms, of which a workgroup
+// spends 7 us of its 16.5 us per tile waiting for the wave that has the last group (10 us against 3 us for any other
+// group); the same with everything a wave needs for both of its groups requested ahead of the tile's barrier: no
+// different (0.81 against 0.82 ms for the call); groups taken from a counter, farthest first: 14.6 us per tile.
+template <int kOutMode>
+__global__ __launch_bounds__(256, 4) void deferred_deep_kernel(const DeferredParams p) {
+  constexpr uint32_t kUnits = 16;
+  __shared__ float4 s_light_of[4][2 * kWaveChunk + 8];  // + one trip: the prefetch of the last trip reads past the list
+  __shared__ uint32_t s_alb[1024], s_mat[1024], s_out[1024];  // the tile's planes, texel y * 32 + x
+  __shared__ float s_dep[1024];
+  __shared__ uint2 s_nrm[1024];
+  __shared__ uint32_t s_next_unit;  // how many of the tile's units have been taken
+  // what every unit would otherwise fetch for itself, one round trip after the other, before it can ask for its first
+  // light records: the tile's depth order, the groups' list lengths and the first 64 entries of each group's list
+  __shared__ uint16_t s_order[1024], s_entry[kStripsPerTile][kWaveChunk];
+  __shared__ uint32_t s_length[kStripsPerTile];
+  constexpr bool kIs8Bit = kOutMode == kOutRgba8 || kOutMode == kOutBgra8;
+  const uint32_t t = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // lane, wave of the workgroup (the same in every lane)
+  float4* const s_light = s_light_of[wv];
+  const float4* __restrict__ lights = reinterpret_cast<const float4*>(p.lights);
+  LoopConsts kc;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.step_scale) : "s"(kStepScale));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.step_bias) : "s"(-kEarlyOut * kStepScale));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.dist_floor) : "s"(kDistFloor));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.radius2_scaled) : "s"(p.radius2 * kRadiusStepScale));
+  const uint32_t n_tiles = p.tiles_x * p.tiles_y;
+  const uint32_t q_end = p.lit_counters[kListClasses];
+#pragma unroll 1
+  for (uint32_t q = blockIdx.x; q < q_end; q += gridDim.x) {
+    const uint32_t tile = p.lit_queue[(size_t)kListClasses * n_tiles + q];
+    const uint32_t tile_y = tile / p.tiles_x, tile_x = tile - tile_y * p.tiles_x;
+    const uint32_t word = p.tile_count[tile];
+#ifdef VKR_X_TIMES  // measurement builds only (tools/tile_phase_times.py deep): the wall clock at the end of each phase of a deep tile's workgroup
+    unsigned long long dstamp[8] = {};
+#define VKR_DSTAMP(i) dstamp[i] = wall_clock64()
+    VKR_DSTAMP(0);
+#else
+#define VKR_DSTAMP(i)
+#endif
+    {
+      // the tile's planes, 16 bytes per thread and request (rows hold whole 4-texel groups): 256 requests each for albedo,
+      // material and depth, 512 for the normals
+      uint32_t c = threadIdx.x;
+      asm volatile("" : "+v"(c));  // addresses derived per tile, not kept from the kernel's entry across the light loop
+      const uint32_t r = c >> 3, x4 = (c & 7u) * 4u;
+      const uint32_t gx = tile_x * 32u + x4, gy = tile_y * 32u + r;
+      if (gx < p.width && gy < p.height) {
+        *reinterpret_cast<uint4*>(s_alb + r * 32u + x4) = *reinterpret_cast<const uint4*>(p.albedo + (size_t)gy * p.pitch_albedo + (size_t)gx * 4u);
+        *reinterpret_cast<uint4*>(s_mat + r * 32u + x4) = *reinterpret_cast<const uint4*>(p.material + (size_t)gy * p.pitch_material + (size_t)gx * 4u);
+        *reinterpret_cast<float4*>(s_dep + r * 32u + x4) = *reinterpret_cast<const float4*>(p.depth + (size_t)gy * p.pitch_depth + (size_t)gx * 4u);
+      }
+#pragma unroll
+      for (uint32_t h = 0; h < 2u; ++h) {  // two 8-byte texels per request
+        const uint32_t c2 = c + 256u * h, r2 = c2 >> 4, x2 = (c2 & 15u) * 2u;
+        const uint32_t hx = tile_x * 32u + x2, hy = tile_y * 32u + r2;
+        if (hx < p.width && hy < p.height)
+          *reinterpret_cast<uint4*>(s_nrm + r2 * 32u + x2) = *reinterpret_cast<const uint4*>(p.normal + (size_t)hy * p.pitch_normal + (size_t)hx * 8u);
+      }
+      reinterpret_cast<uint2*>(s_order)[c] = reinterpret_cast<const uint2*>(p.tile_order + (size_t)tile * 1024u)[c];
+      // (a list's memory is there whatever its length: entries beyond the length are read and never used)
+      reinterpret_cast<uint32_t*>(&s_entry[0][0])[c] =
+          reinterpret_cast<const uint32_t*>(p.group_list + ((size_t)tile * kStripsPerTile + (c >> 5)) * kGroupListCap)[c & 31u];
+      if (c < kStripsPerTile) s_length[c] = p.group_count[(size_t)tile * kStripsPerTile + c];
+      if (c == 0u) s_next_unit = 0u;
+    }
+    VKR_DSTAMP(1);  // plane requests issued, rows stored
+    __syncthreads();
+    VKR_DSTAMP(2);  // planes in LDS
+    const uint32_t tile_pixels = min(32u, p.width - tile_x * 32u) * min(32u, p.height - tile_y * 32u);
+#pragma unroll 1
+    for (uint32_t turn = 0;; ++turn) {
+      (void)turn;
+      uint32_t taken = 0;
+      if (t == 0u) taken = atomicAdd(&s_next_unit, 1u);
+      taken = __builtin_amdgcn_readfirstlane(taken);
+      if (taken >= kUnits) break;
+      const uint32_t unit = kUnits - 1u - taken;
+      if (unit * 64u >= tile_pixels) continue;  // a tile at the image's edge has fewer units (wave-uniform)
+      // the list of the unit's depth group: the part of the tile's list that can reach the group's depth range
+      // (tile_lists_kernel); when that outgrew its capacity, the tile's own list
+      const uint32_t group = unit >> 1;
+      uint32_t count = __builtin_amdgcn_readfirstlane(s_length[group]);
+      const uint16_t* __restrict__ tl = p.group_list + ((size_t)tile * kStripsPerTile + group) * kGroupListCap;
+      const bool own_list = count != kGroupOverflow;
+      if (!own_list) {
+        tl = p.tile_list + (size_t)tile * p.list_cap;
+        count = word & kTileCountMask;
+      }
+      // The lane's pixel: entry unit * 64 + lane of the tile's depth order (id = y * 32 + x within the tile); beyond the
+      // tile's last pixel, the unit's first, not stored.  Derived where needed, through a copy the compiler cannot see
+      // through, rather than kept across the light loop.
+      auto which = [&](uint32_t tq, bool& mine) -> uint32_t {
+        uint32_t first = unit * 64u;
+        asm volatile("" : "+v"(tq), "+s"(first));
+        mine = first + tq < tile_pixels;
+        return (uint32_t)s_order[first + (mine ? tq : 0u)];
       };
-      auto fetch_records = [&](uint32_t base, uint32_t idx, float4& lp, float4& lc) {
+      bool mine0;
+      const uint32_t id0 = which(t, mine0);
+      const float4 black_pos = make_float4(0.0f, 0.0f, 1e18f, 0.0f), black_col = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      auto fetch_records = [&](uint32_t base, float4& lp, float4& lc) {  // one list entry, then its record, per lane
+        uint32_t tq = t;
+        asm volatile("" : "+v"(tq));
         lp = black_pos;
         lc = black_col;
-        if (base + t < count) {
+        if (base + tq < count) {
+          const uint32_t idx = (base == 0u && own_list) ? (uint32_t)s_entry[group][tq] : (uint32_t)tl[base + tq];
           lp = lights[3u * idx];       // pos.xyz, opening_angle (unused)
           lc = lights[3u * idx + 1u];  // color.xyz, penumbra_angle (unused)
         }
       };
-      float4 lp = black_pos, lc = black_col;
-      if (count != 0u) fetch_records(0u, fetch_index(0u), lp, lc);
-      uint32_t width = p.width, full_height = p.full_height;
-      asm volatile("" : "+s"(width), "+s"(full_height));  // their reciprocals are derived per unit, not kept in vector registers
-      const ExactRcp by_width = exact_rcp((float)width), by_height = exact_rcp((float)full_height);
-      Pixel s[2];
-      setup_pixel(s[0], p, clip_coord(w0.xa, by_width), clip_coord(w0.ya + p.row_offset, by_height), dep2.x, mat2.x, nrm.x, nrm.y);
-      setup_pixel(s[1], p, clip_coord(w0.xb, by_width), clip_coord(w0.yb + p.row_offset, by_height), dep2.y, mat2.y, nrm.z, nrm.w);
-      if (!kDeep) {  // the albedo and material words are decoded after the loop: they wait in LDS, one column per lane
-        s_keep_of[0][t] = alb2.x;
-        s_keep_of[1][t] = alb2.y;
-        s_keep_of[2][t] = mat2.x;
-        s_keep_of[3][t] = mat2.y;
+      float4 lp, lc;
+      fetch_records(0u, lp, lc);
+      Pixel s;
+      {
+        uint32_t width = p.width, full_height = p.full_height;
+        asm volatile("" : "+s"(width), "+s"(full_height));  // their reciprocals are derived per unit, not kept in vector registers
+        const ExactRcp by_width = exact_rcp((float)width), by_height = exact_rcp((float)full_height);
+        const uint2 n2 = s_nrm[id0];
+        setup_pixel(s, p, clip_coord(tile_x * 32u + (id0 & 31u), by_width), clip_coord(tile_y * 32u + (id0 >> 5) + p.row_offset, by_height), s_dep[id0],
+                    s_mat[id0], n2.x, n2.y);
       }
-
       uint32_t probe_left = kProbeBudget;
       // a wave whose pixels all have a v.n that is a number <= 1e-6 gets 0 from every light (deferred.comp:43,84) and
       // does not need to know whether one lay in range: it keeps its ambient colour either way
-      if (__ballot(!(s[0].vn <= kEarlyOut) || !(s[1].vn <= kEarlyOut)) == 0ull) {
-        VKR_COUNT_TRIPS((count + 1u) / 2u, 0u, (count + 1u) / 2u);
+      if (__ballot(!(s.vn <= kEarlyOut)) == 0ull) {
+        VKR_COUNT_TRIPS((count + 3u) / 4u, 0u, (count + 3u) / 4u);
         count = 0u;
       }
-      uint32_t next_idx = 0;
       for (uint32_t base = 0; base < count; base += kWaveChunk) {
         const uint32_t n = min(kWaveChunk, count - base);
-        const uint32_t n2 = (n + 1u) & ~1u;
+        const uint32_t n4 = (n + 3u) & ~3u;  // padded to whole trips with black lights (lanes beyond n hold them)
         // one wave: its LDS accesses execute in program order, no barrier is needed between the loop's reads of
         // the previous chunk and these writes
-        if (base != 0u) fetch_records(base, next_idx, lp, lc);
+        if (base != 0u) fetch_records(base, lp, lc);
         s_light[2u * t] = lp;
         s_light[2u * t + 1u] = lc;
-        Probe probe{probe_budget_for(n2 / 2u, probe_left)};
-        if (base + kWaveChunk < count) next_idx = fetch_index(base + kWaveChunk);  // the next chunk's indices, while this one is shaded
+        Probe probe{probe_budget_for(n4 / 4u, probe_left)};
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const float4* rec = s_light;
-        float4 pa = rec[0], ca = rec[1], pb = rec[2], cb = rec[3];
+        float4 q0 = rec[0], c0 = rec[1], q1 = rec[2], c1 = rec[3], q2 = rec[4], c2 = rec[5], q3 = rec[6], c3 = rec[7];
         uint32_t j = 0;
-        for (; j < n2 && probe.budget != 0u; j += 2u) {  // see deferred_kernel: the loop with the test, then the one without
-          const Light AB[2] = {{pa.x, pa.y, pa.z, ca.x, ca.y, ca.z}, {pb.x, pb.y, pb.z, cb.x, cb.y, cb.z}};
-          rec += 4;  // next pair (one pair beyond the list on the last trip: read, never used)
+        for (; j < n4 && probe.budget != 0u; j += 4u) {  // see deferred_kernel: the loop with the test, then the one without
+          const Light four[4] = {{q0.x, q0.y, q0.z, c0.x, c0.y, c0.z}, {q1.x, q1.y, q1.z, c1.x, c1.y, c1.z},
+                                 {q2.x, q2.y, q2.z, c2.x, c2.y, c2.z}, {q3.x, q3.y, q3.z, c3.x, c3.y, c3.z}};
+          rec += 8;  // next trip (one trip beyond the list on the last one: read, never used)
           shade4<true, true>(
-              s[0], s[1], AB, kc, probe, [&] { pa = rec[0], pb = rec[2]; }, [&] { ca = rec[1], cb = rec[3]; });
+              s, s, four, kc, probe, [&] { q0 = rec[0], q1 = rec[2], q2 = rec[4], q3 = rec[6]; }, [&] { c0 = rec[1], c1 = rec[3], c2 = rec[5], c3 = rec[7]; });
         }
-        if (j < n2) {
-          const float4* rec2 = s_light + 2u * j;
-          float4 pa2 = rec2[0], ca2 = rec2[1], pb2 = rec2[2], cb2 = rec2[3];
-          for (; j < n2; j += 2u) {
-            const Light AB[2] = {{pa2.x, pa2.y, pa2.z, ca2.x, ca2.y, ca2.z}, {pb2.x, pb2.y, pb2.z, cb2.x, cb2.y, cb2.z}};
-            rec2 += 4;
-            pa2 = rec2[0];
-            ca2 = rec2[1];
-            pb2 = rec2[2];
-            cb2 = rec2[3];
-            shade4<true, false>(s[0], s[1], AB, kc, probe, [] {}, [] {});
+        if (j < n4) {
+          uint32_t at = 2u * j;  // see deferred_pixel_kernel: one opaque address and eight immediate offsets per trip
+          asm volatile("" : "+v"(at));
+          const float4* rec2 = s_light + at;
+          float4 r0 = rec2[0], d0 = rec2[1], r1 = rec2[2], d1 = rec2[3], r2 = rec2[4], d2 = rec2[5], r3 = rec2[6], d3 = rec2[7];
+          for (; j < n4; j += 4u) {
+            const Light four[4] = {{r0.x, r0.y, r0.z, d0.x, d0.y, d0.z}, {r1.x, r1.y, r1.z, d1.x, d1.y, d1.z},
+                                   {r2.x, r2.y, r2.z, d2.x, d2.y, d2.z}, {r3.x, r3.y, r3.z, d3.x, d3.y, d3.z}};
+            at += 8u;
+            asm volatile("" : "+v"(at));
+            rec2 = s_light + at;
+            r0 = rec2[0], d0 = rec2[1], r1 = rec2[2], d1 = rec2[3], r2 = rec2[4], d2 = rec2[5], r3 = rec2[6], d3 = rec2[7];
+            shade4<true, false>(s, s, four, kc, probe, [] {}, [] {});
           }
         }
         probe_left = probe.budget;
 #ifdef VKR_X_COUNT
-        VKR_COUNT_TRIPS(n2 / 2u, probe.skipped, 0u);
+        VKR_COUNT_TRIPS(n4 / 4u, probe.skipped, 0u);
 #endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
-      const Where w1 = where(t);
-      float rgb[2][3];
-      if (!kDeep) {
-        finish_pixel(s[0], s_keep_of[0][t], s_keep_of[2][t], s[0].in_range > 0.0f, rgb[0]);
-        finish_pixel(s[1], s_keep_of[1][t], s_keep_of[3][t], s[1].in_range > 0.0f, rgb[1]);
-      } else {
-        finish_pixel(s[0], s_alb[w1.ida], s_mat[w1.ida], s[0].in_range > 0.0f, rgb[0]);
-        finish_pixel(s[1], s_alb[w1.idb], s_mat[w1.idb], s[1].in_range > 0.0f, rgb[1]);
-      }
-      if (!kDeep) {
-        if (w1.ina) {
-          const uint32_t x0 = w1.xa, y = w1.ya;
-          const bool both = w1.inb;
-          uint8_t* orow = p.out + (size_t)y * p.pitch_out;
-          if (kIs8Bit) {
-            uint32_t* o = reinterpret_cast<uint32_t*>(orow) + x0;
-            const uint32_t t0 = pack_unorm8<kOutMode>(rgb[0]), t1 = pack_unorm8<kOutMode>(rgb[1]);
-            if (both)
-              *reinterpret_cast<uint2*>(o) = make_uint2(t0, t1);
-            else
-              o[0] = t0;
-          } else if (kOutMode == kOutRgba16f) {
-            uint2* o = reinterpret_cast<uint2*>(orow) + x0;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-              if (i == 0 || both) o[i] = half_texel(rgb[i][0], rgb[i][1], rgb[i][2]);
-            }
-          } else {
-            float4* o = reinterpret_cast<float4*>(orow) + x0;
-            o[0] = make_float4(rgb[0][0], rgb[0][1], rgb[0][2], 1.0f);
-            if (both) o[1] = make_float4(rgb[1][0], rgb[1][1], rgb[1][2], 1.0f);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          if (!(i == 0 ? w1.ina : w1.inb)) continue;
-          const uint32_t x = i == 0 ? w1.xa : w1.xb, y = i == 0 ? w1.ya : w1.yb;
-          uint8_t* orow = p.out + (size_t)y * p.pitch_out;
-          if (kIs8Bit)
-            s_out[i == 0 ? w1.ida : w1.idb] = pack_unorm8<kOutMode>(rgb[i]);  // leaves in whole rows, below
-          else if (kOutMode == kOutRgba16f)
-            reinterpret_cast<uint2*>(orow)[x] = half_texel(rgb[i][0], rgb[i][1], rgb[i][2]);
+      bool mine1;
+      const uint32_t id1 = which(t, mine1);
+      float rgb[3];
+      finish_pixel(s, s_alb[id1], s_mat[id1], s.in_range > 0.0f, rgb);
+      if (mine1) {
+        if (kIs8Bit) {
+          s_out[id1] = pack_unorm8<kOutMode>(rgb);  // leaves in whole rows, below
+        } else {
+          uint8_t* orow = p.out + (size_t)(tile_y * 32u + (id1 >> 5)) * p.pitch_out;
+          const uint32_t x = tile_x * 32u + (id1 & 31u);
+          if (kOutMode == kOutRgba16f)
+            reinterpret_cast<uint2*>(orow)[x] = half_texel(rgb[0], rgb[1], rgb[2]);
           else
-            reinterpret_cast<float4*>(orow)[x] = make_float4(rgb[i][0], rgb[i][1], rgb[i][2], 1.0f);
+            reinterpret_cast<float4*>(orow)[x] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
         }
       }
+#ifdef VKR_X_TIMES
+      dstamp[3u + min(turn, 1u)] = wall_clock64();  // this wave's first / last unit shaded
+#endif
     }
-    }  // pass
-    if (kDeep) {
-      __syncthreads();  // every group's results are in s_out, and nobody reads the planes any more
-      if (kIs8Bit) {
-        uint32_t c = threadIdx.x;
-        asm volatile("" : "+v"(c));
-        const uint32_t r = c >> 3, x4 = (c & 7u) * 4u;
-        const uint32_t gx = tile_x * 32u + x4, gy = tile_y * 32u + r;
-        if (gx < p.width && gy < p.height) {
-          const uint32_t packed[4] = {s_out[r * 32u + x4], s_out[r * 32u + x4 + 1u], s_out[r * 32u + x4 + 2u], s_out[r * 32u + x4 + 3u]};
-          store_rgba8x4(p.out + (size_t)gy * p.pitch_out, gx, min(4u, p.width - gx), packed);
-        }
+    __syncthreads();  // every unit's results are in s_out, and nobody reads the planes any more
+    VKR_DSTAMP(5);
+    if (kIs8Bit) {
+      uint32_t c = threadIdx.x;
+      asm volatile("" : "+v"(c));
+      const uint32_t r = c >> 3, x4 = (c & 7u) * 4u;
+      const uint32_t gx = tile_x * 32u + x4, gy = tile_y * 32u + r;
+      if (gx < p.width && gy < p.height) {
+        const uint32_t packed[4] = {s_out[r * 32u + x4], s_out[r * 32u + x4 + 1u], s_out[r * 32u + x4 + 2u], s_out[r * 32u + x4 + 3u]};
+        store_rgba8x4(p.out + (size_t)gy * p.pitch_out, gx, min(4u, p.width - gx), packed);
       }
-      __syncthreads();  // s_out and the planes are free for the workgroup's next tile
     }
+    __syncthreads();  // s_out and the planes are free for the workgroup's next tile
+#ifdef VKR_X_TIMES
+    VKR_DSTAMP(6);
+    if (VKR_X_TIMES == 2 && t == 0u && tile < 8192u) {
+#pragma unroll
+      for (int i = 0; i < 7; ++i) g_wave_times[32u * tile + 8u * wv + i] = dstamp[i];
+    }
+#endif
   }
 }
 
@@ -1546,7 +1649,7 @@ __global__ __launch_bounds__(256, 5) void tile_lists_kernel(const DeferredParams
         if (s_lit[w] != 0xFFFFFFFFu && (s_class[w] & 0xFFu) == t) queue[slot++] = s_lit[w];
     }
   }
-#ifdef VKR_X_TIMES
+#if defined(VKR_X_TIMES) && VKR_X_TIMES != 2  // (2: the array holds the deep-tile workgroups' stamps instead)
   if (lane == 0u && tile < n_tiles && tile < 32768u) {
     VKR_STAMP(7);  // queue push
 #pragma unroll
@@ -1701,7 +1804,7 @@ hipError_t launch_mode(const DeferredParams& p, const TileListOut* lists, uint32
     // the list-shading waves stride over the strips of the lit tiles
     static const uint32_t per_cu = [] {
       int n = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, deferred_list_kernel<kOutMode, false>, 64, 0) != hipSuccess || n < 1) n = 16;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, deferred_list_kernel<kOutMode>, 64, 0) != hipSuccess || n < 1) n = 16;
       return (uint32_t)n;
     }();
     // The list launch is bound by HBM and the shading launch by the vector units, and they run one after the other.
@@ -1712,10 +1815,10 @@ hipError_t launch_mode(const DeferredParams& p, const TileListOut* lists, uint32
     // four grids' worth of waves: the hardware starts the later ones as the earlier ones finish, which evens out
     // what the static deal leaves uneven (measured 8K x 4096 analytic / uncorrelated depth: x1 0.198 / 1.41-1.78 ms,
     // x2 0.189 / 1.36, x4 0.190 / 1.31, x8 0.191 / 1.29, x64 0.231 / 1.34)
-    hipLaunchKernelGGL((deferred_list_kernel<kOutMode, false>), dim3(min(kStripsPerTile * tiles, cu_count * per_cu * 4u)), dim3(64), 0, stream, p);
+    hipLaunchKernelGGL((deferred_list_kernel<kOutMode>), dim3(min(kStripsPerTile * tiles, cu_count * per_cu * 4u)), dim3(64), 0, stream, p);
     if (deep_tiles_expected) {  // one workgroup of four waves per deep tile; four of them fit a CU
       if (hipError_t e = hipGetLastError()) return e;
-      hipLaunchKernelGGL((deferred_list_kernel<kOutMode, true>), dim3(min(tiles, cu_count * 4u)), dim3(256), 0, stream, p);
+      hipLaunchKernelGGL((deferred_deep_kernel<kOutMode>), dim3(min(tiles, cu_count * 4u)), dim3(256), 0, stream, p);
     }
   }
   return hipGetLastError();
