@@ -115,17 +115,21 @@ typedef struct vkr_image2d {
                                          The call lists the lights that can reach each 32 x 32 pixel tile (up to 65536
                                          lights; from 256 lights up via a coarse level of 128 x 128 pixel bins), writes
                                          the tiles no light reaches straight away (their pixels are their ambient term)
-                                         and shades the others from their lists.  Lists, bins and the queue of lit tiles
-                                         live in context-owned device memory (1 KiB + 8 bytes per tile, 4 bytes per bin
-                                         and light; allocated or grown inside the call, released with the context).
+                                         and shades the others from their lists; a tile whose pixels span more depth
+                                         than the radius is shaded in eight groups of pixels of similar depth, each from
+                                         the part of the list that can reach it.  Lists, bins, the queues of lit tiles,
+                                         the depth order and group lists live in context-owned device memory (5 KiB +
+                                         40 bytes per tile, 4 bytes per bin and light; allocated or grown inside the
+                                         call, released with the context).
                                          VKR_ERR_BAD_STATE while the context's stream is being captured into a HIP
                                          graph: the launches take a value the host advances per call. */
 #define VKR_DEFERRED_NO_TILE_LISTS 2u /* with RADIUS_CUTOFF: apply the cutoff per pixel only and loop over the whole
                                          light table (diagnostic; results are bit-identical to the tiled path) */
 #define VKR_DEFERRED_WHOLE_TILE_WORKGROUPS 4u /* whole-table loop: always one 256-thread workgroup per 32 x 32 pixel
                                          tile.  Without it a launch of fewer than four rounds of such workgroups (a
-                                         small frame, a screen band) runs as single-wave workgroups over 32 x 8 pixel
-                                         tiles, which keeps the last round full (diagnostic; bit-identical results) */
+                                         small frame, a screen band) runs as single-wave workgroups of 64 pixels of a
+                                         row, one per lane, which shortens the end of the launch (diagnostic;
+                                         bit-identical results) */
 
 /* One dispatch of /root/reference/shaders/deferred.comp (main, :98-131) as recorded at
  * /root/reference/src/main.cpp:222-226.  Bindings follow main.cpp:163-167,190-196:
@@ -163,8 +167,8 @@ typedef struct vkr_tile_stats {
   uint32_t list_cap;       /* entries a list holds */
   uint64_t light_pixels;   /* sum over tiles (for deep tiles: over their groups of pixels) of lights walked x pixels inside the image */
   uint64_t pixels;         /* width x height */
-  uint32_t deep_tiles;     /* listed tiles that span more depth than a light reaches: shaded in groups of 128 pixels of
-                              similar depth, each group walking the part of the tile's list that can reach it */
+  uint32_t deep_tiles;     /* listed tiles that span more depth than a light reaches: shaded in eight groups of pixels
+                              of similar depth, each group walking the part of the tile's list that can reach it */
   uint32_t reserved;
 } vkr_tile_stats;
 VKR_API int32_t vkr_deferred_tile_stats(vkr_context* ctx, vkr_tile_stats* out);

@@ -38,7 +38,9 @@ def test_profiled_traffic_reads_the_committed_profile():
         assert k in pmc, k
     if "tiled_resolve_8k" in pmc:  # profiles from this layout on: one entry per radius-cutoff workload
         for name, (w, h, _, _) in b.TILED_WORKLOADS.items():
-            assert 0.3 < pmc[name] / (w * h * 24) < 1.3, name  # dark tiles never read normals and material
+            # dark tiles never read normals and material; a frame of deep tiles reads depth twice and writes and reads its
+            # pixels' depth order on top of the 24 bytes (measured 1.57)
+            assert 0.3 < pmc[name] / (w * h * 24) < (1.7 if name.endswith("_discontinuous") else 1.3), name
     else:
         tiled = sum(pmc[k] for k in b.PMC_TILED)
         assert 0.5 < tiled / (7680 * 4320 * 24) < 0.7
