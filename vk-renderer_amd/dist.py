@@ -154,6 +154,11 @@ class HostTransport:
     def to_numpy(self, tensor) -> np.ndarray:
         return tensor.cpu().numpy()
 
+    def settle(self):
+        """Buffers just allocated are zero-filled on torch's stream: finished before anything else writes them."""
+        if self.device != "cpu":
+            self.torch.cuda.synchronize()
+
 
 class RcclTransport:
     """RCCL on device tensors.  torch sees the library's stream as an external stream: a collective issued
@@ -194,7 +199,15 @@ class RcclTransport:
         return float(t.item())
 
     def to_numpy(self, tensor) -> np.ndarray:
-        return tensor.cpu().numpy()
+        # the copy goes on the library's stream, behind whatever wait() put there: torch's own stream is ordered
+        # neither with it (a non-blocking stream) nor with RCCL's
+        with self.torch.cuda.stream(self.stream):
+            return tensor.cpu().numpy()
+
+    def settle(self):
+        """Buffers just allocated are zero-filled on torch's stream, which is not ordered with the library's stream:
+        finished before a kernel or a transfer writes them."""
+        self.torch.cuda.synchronize(self.device)
 
 
 class GatherPipeline:
@@ -209,6 +222,7 @@ class GatherPipeline:
         self.recv = [[transport.alloc_recv(nbytes) for _ in range(transport.world)] if transport.rank == 0 else None for _ in range(slots)]
         self.works = [None] * slots
         self.steps = 0
+        transport.settle()
 
     def step(self, fill: Callable[[object], None]):
         b = self.steps % self.slots
