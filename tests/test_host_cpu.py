@@ -339,13 +339,13 @@ def test_resolve_kernels_use_no_scratch_memory():
     for name, k in kernels.items():
         flat = re.search(r"deferred_kernelILi(\d)ELb([01])ELi(\d)EE", name)
         pixel = re.search(r"deferred_pixel_kernelILi(\d)ELb([01])EE", name)
-        production = (flat and flat.group(2) == "0") or (pixel and pixel.group(2) == "0") or "deferred_list_kernel" in name or "deferred_deep_kernel" in name or "tile_lists_kernel" in name or "light_bins_kernel" in name
+        production = (flat and flat.group(2) == "0") or (pixel and pixel.group(2) == "0") or "deferred_lists_kernel" in name or "tile_lists_kernel" in name or "light_bins_kernel" in name
         if not production:
             continue  # the whole-table loop with the per-pixel cutoff is a diagnostic, not a production path
         assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0, (name, k)
         assert k["vgpr_count"] <= 128, (name, k)  # four waves per SIMD
         checked += 1
-    assert checked == 8 + 8 + 4 + 1  # four output formats each of: whole-table kernel (four pixels per lane, and one), list shading (strips, and deep tiles), list building; the bins
+    assert checked == 8 + 4 + 4 + 1  # four output formats each of: whole-table kernel (four pixels per lane, and one), list shading (strips and deep tiles in one kernel), list building; the bins
 
 
 @pytest.mark.parametrize("unit", ["cull", "scene", "gbuffer"])

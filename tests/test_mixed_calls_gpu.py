@@ -128,45 +128,59 @@ def test_deterministic_cull_beside_a_long_resolve(vkr, synth, oracle):
     print(f"culls finished while the resolve was still running in {overlapped} of 3 rounds")
 
 
-def test_pipelines_over_the_rccl_transport_with_one_rank(vkr, synth):
+RCCL_ONE_RANK = r"""
+import importlib, os, sys
+import numpy as np
+import torch  # before the library, as in bench.py: one HIP runtime in the process, torch's
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+vkr = importlib.import_module("vk-renderer_amd")
+synth = importlib.import_module("vk-renderer_amd.synth")
+vdist = importlib.import_module("vk-renderer_amd.dist")
+launch = importlib.import_module("vk-renderer_amd.launch")
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(launch.free_port()))
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+ctx = vkr.Context(0)
+tr = vdist.RcclTransport(ctx.stream(), 0)
+
+def device_sync():
+    ctx.wait_idle()
+    torch.cuda.synchronize()
+
+w, h, lights = 416, 203, 40
+case = synth.deferred_case(w, h, lights, config_index=3)
+gb = vkr.GBuffer(ctx, w, h).upload(case["gbuf"])
+lbuf = ctx.buffer_from(case["lights"])
+out = ctx.image(vkr.FORMAT_R8G8B8A8_UNORM, w, h)
+pipe = vdist.BandShardedResolve(tr, w, h, out.pitch, vdist.hip_band_resolver(vkr, ctx, gb, out, lbuf, lights, case["push"], 0))
+assert vdist.timed_steps(tr, pipe, 5, 2, device_sync) > 0
+got = pipe.frame()
+ctx.deferred_resolve(vkr.make_deferred_args(gb, out, lbuf, lights, case["push"]))
+ctx.wait_idle()
+assert np.array_equal(got, out.download(np.uint8, 4))
+scene = synth.cull_case(200000, 300, config_index=5)
+rp = vdist.RangeShardedCull(tr, scene["mesh_base"], 200000, vdist.hip_range_culler(vkr, ctx, scene, scene["planes"], 0))
+assert vdist.timed_steps(tr, rp, 5, 2, device_sync) > 0
+whole = vkr.CullScene(ctx, scene["aabb_min"], scene["aabb_max"], scene["mesh_base"], scene["cmd_template"])
+whole.run(scene["planes"], 0)
+ctx.wait_idle()
+assert rp.commands() == whole.results()["cmds"].tobytes()
+dist.destroy_process_group()
+print("PIPELINES-OK")
+"""
+
+
+def test_pipelines_over_the_rccl_transport_with_one_rank(tmp_path):
     """The band and range pipelines over RcclTransport, as `bench.py --gpus N` runs them, with a process group of one
     rank (all this box has): the library's stream as torch's external stream, the gather issued on it behind the
     kernel, the stream-level wait before a buffer is refilled, the copy out on the same stream.  The gathered frame
-    and command buffer must be those of a direct call."""
-    import importlib
+    and command buffer must be those of a direct call.  In a process of its own, torch first, as in bench.py."""
     import os
-    import torch
-    import torch.distributed as dist
-    vdist = importlib.import_module("vk-renderer_amd.dist")
-    launch = importlib.import_module("vk-renderer_amd.launch")
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(launch.free_port()))
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        ctx = vkr.Context(0)
-        tr = vdist.RcclTransport(ctx.stream(), 0)
-
-        def device_sync():
-            ctx.wait_idle()
-            torch.cuda.synchronize()
-
-        w, h, lights = 416, 203, 40
-        case = synth.deferred_case(w, h, lights, config_index=3)
-        gb = vkr.GBuffer(ctx, w, h).upload(case["gbuf"])
-        lbuf = ctx.buffer_from(case["lights"])
-        out = ctx.image(vkr.FORMAT_R8G8B8A8_UNORM, w, h)
-        pipe = vdist.BandShardedResolve(tr, w, h, out.pitch, vdist.hip_band_resolver(vkr, ctx, gb, out, lbuf, lights, case["push"], 0))
-        assert vdist.timed_steps(tr, pipe, 5, 2, device_sync) > 0
-        got = pipe.frame()
-        ctx.deferred_resolve(vkr.make_deferred_args(gb, out, lbuf, lights, case["push"]))
-        ctx.wait_idle()
-        assert np.array_equal(got, out.download(np.uint8, 4))
-        scene = synth.cull_case(200000, 300, config_index=5)
-        rp = vdist.RangeShardedCull(tr, scene["mesh_base"], 200000, vdist.hip_range_culler(vkr, ctx, scene, scene["planes"], 0))
-        assert vdist.timed_steps(tr, rp, 5, 2, device_sync) > 0
-        whole = vkr.CullScene(ctx, scene["aabb_min"], scene["aabb_max"], scene["mesh_base"], scene["cmd_template"])
-        whole.run(scene["planes"], 0)
-        ctx.wait_idle()
-        assert rp.commands() == whole.results()["cmds"].tobytes()
-    finally:
-        dist.destroy_process_group()
+    import subprocess
+    import sys
+    script = tmp_path / "rccl_one_rank.py"
+    script.write_text(RCCL_ONE_RANK)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and "PIPELINES-OK" in r.stdout, r.stderr[-3000:]

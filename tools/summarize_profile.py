@@ -98,7 +98,7 @@ for k, c in out.items():
         c["clock_GHz_under_pmc"] = c["GRBM_GUI_ACTIVE"] / 8 / (c["duration_us_under_pmc"]["pmc_SQ_WAVES"] * 1e3)
 
 # the radius-cutoff workloads, each profiled alone (bench.py --only-tiled NAME): bytes of one call = sum over its launches
-TILED_KERNELS = ("light_bins_kernel", "tile_lists_kernel", "deferred_list_kernel", "deferred_deep_kernel")
+TILED_KERNELS = ("light_bins_kernel", "tile_lists_kernel", "deferred_lists_kernel")
 for d in sorted(glob.glob(os.path.join(src, "wl_*__*"))):
     if not os.path.isdir(d):
         continue

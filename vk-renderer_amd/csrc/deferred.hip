@@ -442,7 +442,7 @@ __device__ __forceinline__ void store_float4x4(uint8_t* orow, uint32_t x0, uint3
 // The light records (pos.xyz, color.xyz as two float4) go through LDS in lists of up to kChunk,
 // padded to an even count with a black light:
 // One workgroup per tile of the launch grid walks the whole table, chunk after chunk (kRadius: with the cutoff
-// applied per pixel; the production path of the cutoff is tile_lists_kernel + deferred_list_kernel below).
+// applied per pixel; the production path of the cutoff is tile_lists_kernel + deferred_lists_kernel below).
 // Ablations of the light loop at 4K x 256 lights (2.33 ms on the box that ran them): two trips' worth of
 // lights per loop trip (half the loop's scalar instructions and branches per evaluation): 2.366 against 2.360 ms;
 // no idle cycle after the fourth transcendental of a group (the s_setprio that follows already separates it from
@@ -681,7 +681,10 @@ __global__ __launch_bounds__(64 * kWaves, 4) void deferred_kernel(const Deferred
 // shades 64 consecutive pixels of a row, one per lane, and walks the table once, four lights per trip - the same four
 // (pixel, light) evaluations per trip, and per pixel the same sums in the same order, as the kernels above: the
 // bytes are the same.
-constexpr uint32_t kPixelChunk = 128;  // lights per LDS chunk
+#ifndef VKR_X_PIXEL_CHUNK
+#define VKR_X_PIXEL_CHUNK 128
+#endif
+constexpr uint32_t kPixelChunk = VKR_X_PIXEL_CHUNK;  // lights per LDS chunk
 
 template <int kOutMode, bool kRadius>
 __global__ __launch_bounds__(64, 4) void deferred_pixel_kernel(const DeferredParams p) {
@@ -928,12 +931,19 @@ constexpr uint32_t kStripRows = 4, kStripsPerTile = 32 / kStripRows, kWaveChunk 
 constexpr uint32_t kDeepMinList = VKR_X_DEEP_MIN;  // shorter lists are walked whole: narrowing them costs more than it saves
 constexpr float kDeepSpanRadii = 1.0f;    // a tile is deep when its near and far ends are further apart than this many radii
 
+// LDS of one wave in the strips role
+struct StripLds {
+  float s_light[(2 * kWaveChunk + 4) * 4];  // float4 records; +1 pair: the prefetch of the last iteration reads past the list
+  uint32_t s_keep[4][64];                   // albedo and material words, waiting for the end of the loop
+};
+
+// The strips role of deferred_lists_kernel: this wave takes units unit_first, unit_first + unit_stride, ...
 template <int kOutMode>
-__global__ __launch_bounds__(64, 4) void deferred_list_kernel(const DeferredParams p) {
-  __shared__ float4 s_light[2 * kWaveChunk + 4];  // +1 pair: the prefetch of the last iteration reads past the list
-  __shared__ uint32_t s_keep[4][64];              // albedo and material words, waiting for the end of the loop
+__device__ __forceinline__ void shade_strips(const DeferredParams& p, StripLds& lds, uint32_t unit_first, uint32_t unit_stride) {
+  float4* const s_light = reinterpret_cast<float4*>(lds.s_light);
+  uint32_t (&s_keep)[4][64] = lds.s_keep;
   constexpr bool kIs8Bit = kOutMode == kOutRgba8 || kOutMode == kOutBgra8;
-  const uint32_t t = threadIdx.x;
+  const uint32_t t = threadIdx.x & 63u;
   const float4* __restrict__ lights = reinterpret_cast<const float4*>(p.lights);
   const uint32_t L = p.light_count;
   LoopConsts kc;
@@ -953,10 +963,8 @@ __global__ __launch_bounds__(64, 4) void deferred_list_kernel(const DeferredPara
   }
   const uint32_t n_tiles = p.tiles_x * p.tiles_y;
   const uint32_t q_end = kStripsPerTile * class_end[kListClasses - 1];
-  // for the host's next call: how many tiles of this frame qualify as deep (a store to host memory, nobody waits for it)
-  if (blockIdx.x == 0u && threadIdx.x == 0u && p.deep_hint) __hip_atomic_store(p.deep_hint, p.lit_counters[kDeepCounter], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #pragma unroll 1
-  for (uint32_t q = blockIdx.x; q < q_end; q += gridDim.x) {
+  for (uint32_t q = unit_first; q < q_end; q += unit_stride) {
     const uint32_t pos = q / kStripsPerTile, strip = q % kStripsPerTile;
     uint32_t cls = kListClasses - 1u, first = 0u;  // position of the concatenated queues -> (class, index)
 #pragma unroll
@@ -1129,21 +1137,35 @@ __global__ __launch_bounds__(64, 4) void deferred_list_kernel(const DeferredPara
 // spends 7 us of its 16.5 us per tile waiting for the wave that has the last group (10 us against 3 us for any other
 // group); the same with everything a wave needs for both of its groups requested ahead of the tile's barrier: no
 // different (0.81 against 0.82 ms for the call); groups taken from a counter, farthest first: 14.6 us per tile.
-template <int kOutMode>
-__global__ __launch_bounds__(256, 4) void deferred_deep_kernel(const DeferredParams p) {
-  constexpr uint32_t kUnits = 16;
-  __shared__ float4 s_light_of[4][2 * kWaveChunk + 8];  // + one trip: the prefetch of the last trip reads past the list
-  __shared__ uint32_t s_alb[1024], s_mat[1024], s_out[1024];  // the tile's planes, texel y * 32 + x
-  __shared__ float s_dep[1024];
-  __shared__ uint2 s_nrm[1024];
-  __shared__ uint32_t s_next_unit;  // how many of the tile's units have been taken
+// LDS of a workgroup in the deep-tile role
+struct DeepLds {
+  float s_light_of[4][(2 * kWaveChunk + 8) * 4];  // float4 records per wave; + one trip: the prefetch of the last trip reads past the list
+  uint32_t s_alb[1024], s_mat[1024];  // the tile's planes, texel y * 32 + x; a pixel's 8-bit result replaces its albedo word
+  float s_dep[1024];
+  uint32_t s_nrm[1024][2];
   // what every unit would otherwise fetch for itself, one round trip after the other, before it can ask for its first
   // light records: the tile's depth order, the groups' list lengths and the first 64 entries of each group's list
-  __shared__ uint16_t s_order[1024], s_entry[kStripsPerTile][kWaveChunk];
-  __shared__ uint32_t s_length[kStripsPerTile];
+  uint16_t s_order[1024], s_entry[kStripsPerTile][kWaveChunk];
+  uint32_t s_length[kStripsPerTile];
+  uint32_t s_next_unit;  // how many of the tile's units have been taken
+};
+
+// The deep-tile role of deferred_lists_kernel: this workgroup takes tiles tile_first, tile_first + tile_stride, ... of the deep queue
+template <int kOutMode>
+__device__ __forceinline__ void shade_deep_tiles(const DeferredParams& p, DeepLds& lds, uint32_t tile_first, uint32_t tile_stride) {
+  constexpr uint32_t kUnits = 16;
+  uint32_t* const s_alb = lds.s_alb;
+  uint32_t* const s_mat = lds.s_mat;
+  uint32_t* const s_out = lds.s_alb;
+  float* const s_dep = lds.s_dep;
+  uint2* const s_nrm = reinterpret_cast<uint2*>(lds.s_nrm);
+  uint16_t* const s_order = lds.s_order;
+  uint16_t (&s_entry)[kStripsPerTile][kWaveChunk] = lds.s_entry;
+  uint32_t* const s_length = lds.s_length;
+  uint32_t& s_next_unit = lds.s_next_unit;
   constexpr bool kIs8Bit = kOutMode == kOutRgba8 || kOutMode == kOutBgra8;
   const uint32_t t = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // lane, wave of the workgroup (the same in every lane)
-  float4* const s_light = s_light_of[wv];
+  float4* const s_light = reinterpret_cast<float4*>(lds.s_light_of[wv]);
   const float4* __restrict__ lights = reinterpret_cast<const float4*>(p.lights);
   LoopConsts kc;
   asm volatile("v_mov_b32 %0, %1" : "=v"(kc.step_scale) : "s"(kStepScale));
@@ -1153,7 +1175,7 @@ __global__ __launch_bounds__(256, 4) void deferred_deep_kernel(const DeferredPar
   const uint32_t n_tiles = p.tiles_x * p.tiles_y;
   const uint32_t q_end = p.lit_counters[kListClasses];
 #pragma unroll 1
-  for (uint32_t q = blockIdx.x; q < q_end; q += gridDim.x) {
+  for (uint32_t q = tile_first; q < q_end; q += tile_stride) {
     const uint32_t tile = p.lit_queue[(size_t)kListClasses * n_tiles + q];
     const uint32_t tile_y = tile / p.tiles_x, tile_x = tile - tile_y * p.tiles_x;
     const uint32_t word = p.tile_count[tile];
@@ -1341,6 +1363,27 @@ __global__ __launch_bounds__(256, 4) void deferred_deep_kernel(const DeferredPar
   }
 }
 
+// One launch shades everything the tile kernel queued.  Workgroups of four waves; the first `deep_groups` workgroups of
+// the grid take whole deep tiles, the others shade strips, each wave on its own.  A deep tile is the longer piece of
+// work (12 us against 3-5 for a strip), so those workgroups go first, and strips workgroups take their places as they
+// end: as two launches the two kinds ran one after the other, neither filling the device (8K x 4096 on the analytic
+// scene: 24 + 37 us; 4K x 4096: 0.088 -> 0.079 ms for the call).  Interleaving the roles in launch order instead (one
+// deep-tile workgroup in front of every four strips workgroups) was slower where every tile is deep (0.82 against
+// 0.67 ms: the deep-tile workgroups reach the CUs unevenly).
+template <int kOutMode>
+__global__ __launch_bounds__(256, 4) void deferred_lists_kernel(const DeferredParams p, uint32_t deep_groups) {
+  constexpr size_t kLdsBytes = sizeof(DeepLds) > 4 * sizeof(StripLds) ? sizeof(DeepLds) : 4 * sizeof(StripLds);
+  __shared__ __align__(16) unsigned char lds_raw[kLdsBytes];
+  // for the host's next call: how many tiles of this frame qualify as deep (a store to host memory, nobody waits for it)
+  if (blockIdx.x == 0u && threadIdx.x == 0u && p.deep_hint) __hip_atomic_store(p.deep_hint, p.lit_counters[kDeepCounter], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (blockIdx.x < deep_groups) {
+    shade_deep_tiles<kOutMode>(p, *reinterpret_cast<DeepLds*>(lds_raw), blockIdx.x, deep_groups);
+  } else {
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    shade_strips<kOutMode>(p, reinterpret_cast<StripLds*>(lds_raw)[wv], (blockIdx.x - deep_groups) * 4u + wv, (gridDim.x - deep_groups) * 4u);
+  }
+}
+
 // ------------------------------------------------------------------ tile light lists (radius cutoff)
 // One wave per 32 x 32 pixel tile (four tiles per workgroup; nothing is shared between the waves but the queue
 // push at the end).  Lane l owns the 4-pixel groups (4*(l&7) .. +3, (l>>3) + 8k), k = 0..3, of the tile: four
@@ -1350,7 +1393,7 @@ __global__ __launch_bounds__(256, 4) void deferred_deep_kernel(const DeferredPar
 // tile's list.  A tile that no light reaches is finished here: every light sum of deferred.comp:120-129 is
 // zero for its pixels, whatever their positions and normals are, so they are their ambient term
 // (deferred.comp:107) - 12 bytes per pixel instead of 24, and the shading kernel never sees the tile.  The other
-// tiles are queued for deferred_list_kernel.
+// tiles are queued for deferred_lists_kernel.
 template <int kOutMode>
 __global__ __launch_bounds__(256, 5) void tile_lists_kernel(const DeferredParams p, const TileListOut o) {
   __shared__ uint32_t s_lit[4], s_class[4];
@@ -1801,25 +1844,17 @@ hipError_t launch_mode(const DeferredParams& p, const TileListOut* lists, uint32
     const uint32_t tiles = p.tiles_x * p.tiles_y;
     hipLaunchKernelGGL((tile_lists_kernel<kOutMode>), dim3((tiles + 3u) / 4u), dim3(256), 0, stream, p, *lists);
     if (hipError_t e = hipGetLastError()) return e;
-    // the list-shading waves stride over the strips of the lit tiles
-    static const uint32_t per_cu = [] {
-      int n = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, deferred_list_kernel<kOutMode>, 64, 0) != hipSuccess || n < 1) n = 16;
-      return (uint32_t)n;
-    }();
     // The list launch is bound by HBM and the shading launch by the vector units, and they run one after the other.
     // Splitting the frame in two and putting the second half's two launches on a second stream, behind an event
     // after the first half's lists, so that they could run beside the first half's shading, was measured: 62-79 /
     // 110 / 192 us against 38.5 / 86 / 169 us (4K x 256, 4K x 4096, 8K x 4096) - the shading waves hold every
     // vector register of a SIMD, nothing of the other launch fits beside them, and the events cost their own time.
-    // four grids' worth of waves: the hardware starts the later ones as the earlier ones finish, which evens out
-    // what the static deal leaves uneven (measured 8K x 4096 analytic / uncorrelated depth: x1 0.198 / 1.41-1.78 ms,
-    // x2 0.189 / 1.36, x4 0.190 / 1.31, x8 0.191 / 1.29, x64 0.231 / 1.34)
-    hipLaunchKernelGGL((deferred_list_kernel<kOutMode>), dim3(min(kStripsPerTile * tiles, cu_count * per_cu * 4u)), dim3(64), 0, stream, p);
-    if (deep_tiles_expected) {  // one workgroup of four waves per deep tile; four of them fit a CU
-      if (hipError_t e = hipGetLastError()) return e;
-      hipLaunchKernelGGL((deferred_deep_kernel<kOutMode>), dim3(min(tiles, cu_count * 4u)), dim3(256), 0, stream, p);
-    }
+    // Strips: four grids' worth of waves (a CU holds four workgroups of four): the hardware starts the later ones as
+    // the earlier ones finish, which evens out what the static deal leaves uneven (measured 8K x 4096 analytic /
+    // uncorrelated depth: x1 0.198 / 1.41-1.78 ms, x2 0.189 / 1.36, x4 0.190 / 1.31, x8 0.191 / 1.29, x64 0.231 / 1.34).
+    const uint32_t strip_groups = min((kStripsPerTile * tiles + 3u) / 4u, cu_count * 16u);
+    const uint32_t deep_groups = deep_tiles_expected ? min(tiles, cu_count * 4u) : 0u;  // one workgroup per deep tile; a CU holds four
+    hipLaunchKernelGGL((deferred_lists_kernel<kOutMode>), dim3(deep_groups + strip_groups), dim3(256), 0, stream, p, deep_groups);
   }
   return hipGetLastError();
 }
