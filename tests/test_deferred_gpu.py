@@ -311,6 +311,25 @@ def test_depth_grouped_tiles(vkr, synth):
         assert np.array_equal(got, want)
     st = ctx.tile_stats()
     assert st["deep_tiles"] > 0 and st["max_list"] >= 200 and st["overflow_tiles"] == 0
+    # texels that are not numbers inside deep tiles (the depth order and the groups' depth ranges are built from the
+    # very values that are broken here): depth NaN / +inf / negative, cleared normals (0, 0, 0), a NaN normal - the
+    # same bits as the whole-table loop, NaN payloads included, and the same 8-bit frame
+    broken = dict(noisy, gbuf={k: v.copy() for k, v in noisy["gbuf"].items()})
+    rng = np.random.default_rng(11)
+    ys, xs = rng.integers(0, h, 400), rng.integers(0, w, 400)
+    broken["gbuf"]["depth"][ys[:100], xs[:100]] = np.nan
+    broken["gbuf"]["depth"][ys[100:150], xs[100:150]] = np.inf
+    broken["gbuf"]["depth"][ys[150:200], xs[150:200]] = -0.5
+    broken["gbuf"]["normal"][ys[200:300], xs[200:300], :3] = 0
+    broken["gbuf"]["normal"][ys[300:400], xs[300:400], 1] = np.nan
+    broken["gbuf"]["depth"][64:96, 32:64] = np.nan  # a whole tile without a single depth that is a number
+    for fmt, as_bits in ((vkr.FORMAT_R32G32B32A32_SFLOAT, np.uint32), (vkr.FORMAT_R8G8B8A8_UNORM, np.uint8)):
+        want, _ = run_deferred_gpu(vkr, ctx, broken, fmt, flags=flat_flags)
+        for _ in range(2):
+            got, _ = run_deferred_gpu(vkr, ctx, broken, fmt, flags=tiled)
+            assert np.array_equal(got.view(as_bits), want.view(as_bits)), fmt
+        if as_bits is np.uint32:
+            assert np.isnan(want[..., :3]).any() and ctx.tile_stats()["deep_tiles"] > 20
 
 
 def test_radius_argument_range(vkr, synth, ctx):
