@@ -806,13 +806,6 @@ __device__ __forceinline__ float position_error_bound(float max_abs_coord, float
   return kPositionEps * fma_(max_abs_coord, terms_w, terms_xyz) / min_abs_w + kPositionEps * max_abs_coord;
 }
 
-// Bit patterns that order like the numbers they stand for (not-a-number aside), for integer min / max.
-__device__ __forceinline__ uint32_t ordered_bits(float v) {
-  const uint32_t b = __float_as_uint(v);
-  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float from_ordered_bits(uint32_t o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o); }
-
 __device__ __forceinline__ float lane_value(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 
 // One wave computes the bounds of tile (tile_x, tile_y) from its depth range.  The pixel positions are the
@@ -1398,7 +1391,8 @@ template <int kOutMode>
 __global__ __launch_bounds__(256, 5) void tile_lists_kernel(const DeferredParams p, const TileListOut o) {
   __shared__ uint32_t s_lit[4], s_class[4];
   __shared__ uint32_t s_cell[4][64];  // per wave: pixels per depth cell, then where each cell's pixels begin
-  __shared__ uint32_t s_range[4][16];  // per wave: depth range (bit patterns) of each of the eight groups of a deep tile
+  __shared__ uint16_t s_sorted_id[4][1024];  // per wave, deep tiles: the tile's pixels (y * 32 + x) in depth order,
+  __shared__ float s_sorted_depth[4][1024];  // and their depths in that order
   __shared__ uint16_t s_tlist[4][kChunk];  // per wave: the tile's list as it is written out (kChunk = list_cap)
   const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
   const uint32_t n_tiles = p.tiles_x * p.tiles_y;
@@ -1526,43 +1520,61 @@ __global__ __launch_bounds__(256, 5) void tile_lists_kernel(const DeferredParams
         s_cell[wv][lane] = incl - mine;  // where the cell's pixels begin
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        uint16_t* __restrict__ order = o.tile_order + (size_t)tile * 1024u;
-  #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-  #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            if (in[k] && x0 + (uint32_t)i < p.width)
-              order[s_cell[wv][rank[k][i] >> 16] + (rank[k][i] & 0xFFFFu)] = (uint16_t)((((lane >> 3) + 8u * k) << 5) | ((lane & 7u) * 4u + (uint32_t)i));
-          }
-        }
-        VKR_STAMP(4);  // pixel order written
-        // Depth range of each group of 128 consecutive pixels of that order (depths are not negative: their bit
-        // patterns order like the numbers), then the group's own bounds - the tile's extent on screen, the group's in
-        // depth - and the part of the tile's list that can reach them, in list order.
-        if (lane < 16u) s_range[wv][lane] = (lane & 1u) ? 0u : 0xFFFFFFFFu;  // [2g] = min, [2g + 1] = max, as ordered_bits()
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        // The pixels go to their places of the depth order in LDS first: from there lane l writes places 16 l .. 16 l + 15
+        // out as 32 contiguous bytes (the wave: the tile's 2 KiB in one piece; scattered straight to memory they were
+        // 1024 two-byte stores), and the same lane's sixteen depths are all of one group (128 = 8 lanes' worth), so a
+        // group's depth range is a minimum and maximum over eight lanes - no atomics.
   #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float d4[4] = {dep[k].x, dep[k].y, dep[k].z, dep[k].w};
   #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            if (in[k] && x0 + (uint32_t)i < p.width && d4[i] == d4[i]) {  // a pixel whose depth is not a number is lit by nothing
-              const uint32_t g = (s_cell[wv][rank[k][i] >> 16] + (rank[k][i] & 0xFFFFu)) >> 7;
-              atomicMin(&s_range[wv][2u * g], ordered_bits(d4[i]));
-              atomicMax(&s_range[wv][2u * g + 1u], ordered_bits(d4[i]));
+            if (in[k] && x0 + (uint32_t)i < p.width) {
+              const uint32_t at = s_cell[wv][rank[k][i] >> 16] + (rank[k][i] & 0xFFFFu);
+              s_sorted_id[wv][at] = (uint16_t)((((lane >> 3) + 8u * k) << 5) | ((lane & 7u) * 4u + (uint32_t)i));
+              s_sorted_depth[wv][at] = d4[i];
             }
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        const uint32_t tile_pixels = min(32u, p.width - tile_x * 32u) * min(32u, p.height - tile_y * 32u);
+        {
+          const uint4* ids = reinterpret_cast<const uint4*>(&s_sorted_id[wv][16u * lane]);
+          uint4* out_ids = reinterpret_cast<uint4*>(o.tile_order + (size_t)tile * 1024u + 16u * lane);
+          if (16u * lane < tile_pixels) {  // (places beyond the tile's last pixel hold whatever LDS held: never read)
+            out_ids[0] = ids[0];
+            out_ids[1] = ids[1];
+          }
+        }
+        VKR_STAMP(4);  // pixel order written
+        // Depth range of each group of 128 consecutive pixels of that order; a depth that is not a number (such a
+        // pixel is lit by nothing) takes no part, fminf / fmaxf drop it.
+        float gmin = INFINITY, gmax = -INFINITY;
+  #pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 d = *reinterpret_cast<const float4*>(&s_sorted_depth[wv][16u * lane + 4u * j]);
+          const float dd[4] = {d.x, d.y, d.z, d.w};
+  #pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (16u * lane + 4u * j + (uint32_t)i < tile_pixels) {
+              gmin = fminf(gmin, dd[i]);
+              gmax = fmaxf(gmax, dd[i]);
+            }
+          }
+        }
+  #pragma unroll
+        for (int off = 1; off <= 4; off <<= 1) {  // over the group's eight lanes
+          gmin = fminf(gmin, __shfl_xor(gmin, off));
+          gmax = fmaxf(gmax, __shfl_xor(gmax, off));
+        }
         // All eight groups' boxes at once: lane 8g + 2c + k unprojects corner c of the tile at group g's least (k = 0) or
         // greatest (k = 1) depth; the box of a group is the hull of its eight points plus the error pad of the positions
         // (the tile's side faces do not depend on depth: the tile's list has passed them already).
         float glo[3], ghi[3];
         {
-          const uint32_t g = lane >> 3, c = (lane >> 1) & 3u;
-          const float gd = from_ordered_bits(s_range[wv][2u * g + (lane & 1u)]);
+          const uint32_t c = (lane >> 1) & 3u;
+          const float gd = (lane & 1u) ? gmax : gmin;  // (every lane of 8g .. 8g + 7 holds group g's range)
           const float xa = (float)(tile_x * 32u) / (float)p.width * 2.0f - 1.0f;
           const float xb = (float)min(tile_x * 32u + 32u, p.width) / (float)p.width * 2.0f - 1.0f;
           const float ya = (float)(tile_y * 32u + p.row_offset) / (float)p.full_height * 2.0f - 1.0f;
@@ -1604,7 +1616,6 @@ __global__ __launch_bounds__(256, 5) void tile_lists_kernel(const DeferredParams
           }
         }
         VKR_STAMP(5);  // group ranges and boxes
-        const uint32_t tile_pixels = min(32u, p.width - tile_x * 32u) * min(32u, p.height - tile_y * 32u);
         const uint32_t groups = (tile_pixels + 127u) / 128u;
         uint32_t kept[8] = {};  // wave-uniform
         for (uint32_t base = 0; base < count; base += 64u) {
