@@ -900,13 +900,14 @@ __device__ __forceinline__ TileBounds tile_bounds(const DeferredParams& p, uint3
 }
 
 // ------------------------------------------------------------------ shading from tile light lists (radius cutoff)
-// One wave per workgroup; the unit of work is a 32 x 4 pixel strip of a lit tile: lane l owns the two pixels
+// Strips: every wave works on its own (four to a workgroup, sharing nothing - see deferred_lists_kernel); the unit of
+// work is a 32 x 4 pixel strip of a lit tile: lane l owns the two pixels
 // (2*(l&15), 2*(l&15)+1) of row l>>4 of the strip, shaded as one pair, two lights per loop trip (the same four
 // evaluations per trip as the whole-table kernel).  A lit tile is 8 units.  What bounds this launch on sparse
 // frames is not arithmetic but the chain of dependent memory round trips in front of every unit (queue entry ->
 // list length -> light indices -> light records), a few microseconds each time: with 256-thread workgroups
 // taking whole or half tiles, a CU had 3-4 such chains in flight and the launch took (units per workgroup) x
-// (chain), 34 us for 690 lit tiles of at most 6 lights.  Single-wave workgroups put 16 chains in flight per CU,
+// (chain), 34 us for 690 lit tiles of at most 6 lights.  Independent waves put 16 chains in flight per CU,
 // need no barriers, and their list chunk of 64 lights is one record per lane.
 // Units are dealt out statically: wave w of the grid takes units w, w + G, ... of the lit tiles in queue order,
 // heaviest list class first (the eight strips of a tile land on neighbouring waves, so its list and its plane
