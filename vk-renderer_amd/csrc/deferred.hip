@@ -1131,6 +1131,10 @@ __device__ __forceinline__ void shade_strips(const DeferredParams& p, StripLds& 
 // spends 7 us of its 16.5 us per tile waiting for the wave that has the last group (10 us against 3 us for any other
 // group); the same with everything a wave needs for both of its groups requested ahead of the tile's barrier: no
 // different (0.81 against 0.82 ms for the call); groups taken from a counter, farthest first: 14.6 us per tile.
+// In the present form, also tried: the records of each group's first 16 lights fetched with the planes, so that a unit
+// with a short list starts without a round trip of its own - slower on every frame (0.676 against 0.658 ms here, 0.146
+// against 0.139 ms on the analytic 8K frame): the second round trip ahead of the tile's barrier stalls all four waves,
+// while a unit's own fetch is covered by the other waves' work.
 // LDS of a workgroup in the deep-tile role
 struct DeepLds {
   float s_light_of[4][(2 * kWaveChunk + 8) * 4];  // float4 records per wave; + one trip: the prefetch of the last trip reads past the list
