@@ -19,17 +19,19 @@ def main():
     lib = vkr.lib()
     lib.vkr_x_wave_times.argtypes = [C.c_void_p, C.c_uint]
     ctx = vkr.Context(0)
-    W, H, L = 3840, 2160, 256
+    W, H, L = 3840, 2160, int(sys.argv[2]) if len(sys.argv) > 2 else 256
     case = synth.deferred_case(W, H, L, config_index=1)
     gb = vkr.GBuffer(ctx, W, H).upload(case["gbuf"])
     lights = ctx.buffer_from(case["lights"])
     img = ctx.image(vkr.FORMAT_R8G8B8A8_UNORM, W, H)
     rows = int(sys.argv[1]) if len(sys.argv) > 1 else 270
-    a = vkr.make_deferred_args(gb, img, lights, L, case["push"], row0=540, rows=rows)
+    a = vkr.make_deferred_args(gb, img, lights, L, case["push"], row0=(540 if rows <= 1620 else 0), rows=rows)
     for _ in range(20):
         ctx.deferred_resolve(a)
     ctx.wait_idle()
-    waves = ((rows + 7) // 8) * (W // 32)
+    # the build under test decides the shape: single-wave workgroups of 64 pixels of a row for short launches (they
+    # do not record), four-wave workgroups over 32 x 32 tiles otherwise
+    waves = ((rows + 31) // 32) * (W // 32) * 4
     buf = np.zeros((waves, 4), np.uint64)
     assert lib.vkr_x_wave_times(buf.ctypes.data_as(C.c_void_p), waves) == 0
     start, end, where, cycles = buf[:, 0].astype(np.int64), buf[:, 1].astype(np.int64), buf[:, 2], buf[:, 3].astype(np.int64)
@@ -42,7 +44,8 @@ def main():
     sh = (hw >> 12) & 1
     se = (hw >> 13) & 7
     key = (((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd
-    res = {"waves": waves, "start_us": {"p50": float(np.median(us(start))), "max": float(us(start).max())},
+    alive = [(int(((start <= t0 + k * 100) & (end > t0 + k * 100)).sum())) for k in range(0, int((end.max() - t0) / 100) + 1, max(1, int((end.max() - t0) / 100) // 40))]
+    res = {"waves": waves, "lights": L, "waves_alive_over_time": alive, "start_us": {"p50": float(np.median(us(start))), "max": float(us(start).max())},
            "end_us": {"min": float(us(end).min()), "p10": float(np.percentile(us(end), 10)), "p50": float(np.median(us(end))),
                       "p90": float(np.percentile(us(end), 90)), "max": float(us(end).max())},
            "lifetime_us": {"min": float(((end - start) / 100.0).min()), "p50": float(np.median((end - start) / 100.0)), "max": float(((end - start) / 100.0).max())},
