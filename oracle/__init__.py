@@ -46,6 +46,7 @@ class DeferredArgs(C.Structure):
         ("y0", C.c_int32), ("y1", C.c_int32),
         ("flags", C.c_uint32),
         ("out_f32", C.c_void_p), ("out_f64", C.c_void_p), ("out_rgba8", C.c_void_p), ("near_threshold", C.c_void_p),
+        ("view_sensitivity", C.c_void_p),
     ]
 
 
@@ -88,7 +89,9 @@ def deferred(gbuf: dict, lights: np.ndarray, push: np.ndarray, *, mode: str = "f
     lights: (L,12) f32 (48-byte records).  push: (20,) f32 (80-byte block).
     mode: 'f32' | 'f64' | 'mix'.  rows: (y0,y1) or None for the whole frame.
     Returns dict with the requested outputs (full-frame arrays; only `rows` filled)
-    plus 'near_threshold'.
+    plus 'near_threshold'.  want may also name 'view_sensitivity': (H,W,3) f32, how far each
+    channel moves when the unit view vector moves by 2^-23 across itself (the conditioning
+    probe of deferred_oracle_body.inc; costs four more evaluations per pixel).
     """
     L = lib()
     H, W = gbuf["depth"].shape
@@ -100,6 +103,7 @@ def deferred(gbuf: dict, lights: np.ndarray, push: np.ndarray, *, mode: str = "f
     out_f64 = np.zeros((H, W, 4), np.float64) if "f64" in want else None
     out_u8 = np.zeros((H, W, 4), np.uint8) if "rgba8" in want else None
     near = np.zeros((H, W), np.uint8)
+    sens = np.zeros((H, W, 3), np.float32) if "view_sensitivity" in want else None
     fn = getattr(L, "oracle_deferred_" + mode)
 
     def run(ya, yb):
@@ -115,6 +119,7 @@ def deferred(gbuf: dict, lights: np.ndarray, push: np.ndarray, *, mode: str = "f
         a.flags = 1 if radius_cutoff else 0
         a.out_f32, a.out_f64, a.out_rgba8 = _ptr(out_f32), _ptr(out_f64), _ptr(out_u8)
         a.near_threshold = _ptr(near)
+        a.view_sensitivity = _ptr(sens)
         fn(C.byref(a))
 
     if threads <= 1 or (y1 - y0) < 2 * threads:
@@ -130,6 +135,8 @@ def deferred(gbuf: dict, lights: np.ndarray, push: np.ndarray, *, mode: str = "f
     if out_u8 is not None:
         out["rgba8"] = out_u8
     out["near_threshold"] = near
+    if sens is not None:
+        out["view_sensitivity"] = sens
     return out
 
 

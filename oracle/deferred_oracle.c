@@ -133,6 +133,7 @@ typedef struct {
   double* out_f64;     /* W*H*4 doubles or NULL */
   uint8_t* out_rgba8;  /* W*H*4 bytes or NULL */
   uint8_t* near_threshold;
+  float* view_sensitivity; /* W*H*3 floats or NULL: see the conditioning probe in deferred_oracle_body.inc */
 } oracle_deferred_args;
 
 #define REAL float

@@ -4,7 +4,7 @@
 // This file is compiled with -ffp-contract=off: every fused multiply-add below is an explicit
 // __builtin_fmaf, so the depth -> world-position step can reproduce the reference's binary32
 // evaluation order bit for bit (it is ill-conditioned: w = a*z + b cancels as z -> 1), while the
-// per-light loop is written in a cancellation-free form that needs 4 transcendental and 60 plain
+// per-light loop is written in a cancellation-free form that needs 4 transcendental and 57 plain
 // VALU instructions per (pixel, light).
 //
 // Per-light algebra (unit vectors v, l, n; c = l.n; vn = v.n; H = v + l un-normalised, split into
@@ -18,7 +18,11 @@
 //   G   = 1 / ((Lambda(vn)+1)(Lambda(c)+1))                              (deferred.comp:72-76)
 // so  specular = F * D * G * 0.25 / vn = F * [HH^2 * c / (dn^2 (c + q))] * Kspec,
 //     q = sqrt(a2 c^2 + 1),  Kspec = a2 / (PI (vn + sqrt(a2 vn^2 + 1)))  (per pixel)
-// and F = Cs + (1 - Cs) (1 - v.h)^5 splits the light sum into two colour-weighted sums.
+// and F = Cs + (1 - Cs) (1 - v.h)^5 splits the specular sum into two colour-weighted sums, of which the Cs part
+// joins the diffuse sum: diffuseColor = albedo (1 - m) and Cs = albedo m share the albedo, so with the per-pixel
+// scalars A = (1 - m) PI ef and B = m Kspec
+//   colour = ambient + albedo * sum_j c_j (A diffuse_j + B spec_j) + (Kspec - albedo B) * sum_j c_j spec_j (1 - v.h)^5
+// - two sums of three channels per pixel, and A rides for nothing inside the diffuse weight's own multiply-adds.
 // The light vector is rotated into a per-pixel orthonormal frame (T, B, N) so that Ht is obtained
 // directly as (l.T + v.T, l.B + v.B) instead of as |H|^2 - Hn^2.
 //
@@ -50,8 +54,12 @@ constexpr float kPi = 3.14159f;  // deferred.comp:3 (truncated on purpose)
 constexpr float kAmbient = 0.05f;
 constexpr float kAlphaFloor = 0.0064f;
 constexpr float kEarlyOut = 1e-6f;
-constexpr float kDistFloor = 1e-7f;        // deferred.comp:122
-constexpr float kInvDistFloor = 1e7f;      // 1 / kDistFloor
+constexpr float kInvDistFloor = 1e7f;      // 1 / 1e-7, the floor of dist^2 (deferred.comp:122)
+// The frame vectors T, B, N of a pixel are kept times sqrt(1e7): the light vector's components in the frame then
+// come out times sqrt(1e7), the sum of their squares is dist^2 * 1e7 (the frame is orthonormal to rounding), its
+// rsq is sqrt(1e-7) / dist, the cosines (component * rsq) are unscaled, and the distance floor of deferred.comp:122,
+// min(1 / dist^2, 1e7) * 1e-7, is the clamp of rsq * rsq: one instruction.
+constexpr float kFrameScale = 3162.27766f;
 constexpr float kStepScale = 0x1p100f;     // (c - 1e-6) * 2^100 saturates the clamp for any c > 1e-6
 constexpr float kRadiusStepScale = 0x1p80f;
 constexpr int kChunk = 512;                // lights per LDS chunk: 2 float4 each = 16 KiB
@@ -109,14 +117,16 @@ __device__ __forceinline__ float exact_div(float a, const ExactRcp& d) {
 struct Pixel {
   // geometry
   float px, py, pz;            // world position (bit-identical to the binary32 reference order)
-  float tx, ty, tz;            // tangent frame
+  float tx, ty, tz;            // tangent frame, every vector times kFrameScale (see there)
   float bx, by, bz;
-  float nx, ny, nz;            // shading normal = -normalize(gbuffer normal)
-  float vt, vb, vn;            // view direction in the frame
+  float nx, ny, nz;            // shading normal = -normalize(gbuffer normal), times kFrameScale
+  float vt, vb, vn;            // view direction in the (unscaled) frame
   // material
-  float a2, rh, ebm1, pv;      // alpha^2, roughness/2, energyBias-1, (1-vn)^5
-  // accumulators: 1e-7 * sum_j color_j * {diffuse, spec, spec*(1-v.h)^5} scalar weights
-  float ad[3], as0[3], as1[3];
+  float a2, rh, ebm1;          // alpha^2, roughness/2, energyBias-1
+  float ka, kapv, kb;          // A = (1-metal) PI ef 1e7, A (1-vn)^5, B = metal Kspec 1e7 (see shade4 / finish_pixel)
+  // sums over the lights, in table order, of colour_j times a scalar weight: s1 takes A*diffuse + B*spec (everything
+  // the albedo multiplies), s2 takes spec*(1-v.h)^5; both weights carry the 1e-7 of the distance floor
+  float s1[3], s2[3];
   float in_range;              // radius cutoff only: > 0 once any light lay inside the radius
 };
 
@@ -128,7 +138,7 @@ struct Light {
 // Every weight carries a factor 1e-7 (the distance floor is applied as clamp(inv^2 * 1e-7), which
 // equals min(1/d^2, 1e7) * 1e-7); finish_pixel() multiplies it back.
 struct LoopConsts {
-  float step_scale, step_bias, dist_floor, radius2_scaled;
+  float step_scale, step_bias, radius2_scaled;
 };
 
 // Wave-uniform state of the "every light of this trip is behind every surface of this wave" test.
@@ -176,31 +186,34 @@ template <bool kRadius, bool kProbe, int kLights, class FetchPos, class FetchCol
 __device__ __forceinline__ void shade4(Pixel& a, Pixel& b, const Light (&L)[kLights], const LoopConsts& kc, Probe& probe, FetchPos&& fetch_next_pos,
                                        FetchCol&& fetch_next_col) {
   static_assert(kLights == 2 || kLights == 4, "two lights on two pixels, or four on one");
-  float dll[4], lt[4], lb[4], ln[4], inv[4];
+  float dll[4], lt[4], lb[4], ln[4], inv[4], near[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const Pixel& s = (kLights == 2 && (k & 1)) ? b : a;
     const Light& l = L[kLights == 2 ? (k >> 1) : k];
     const float wx = l.px - s.px, wy = l.py - s.py, wz = l.pz - s.pz;
-    dll[k] = fma_(wz, wz, fma_(wy, wy, wx * wx));
     lt[k] = fma_(wz, s.tz, fma_(wy, s.ty, wx * s.tx));
     lb[k] = fma_(wz, s.bz, fma_(wy, s.by, wx * s.bx));
     ln[k] = fma_(wz, s.nz, fma_(wy, s.ny, wx * s.nx));
+    if (kRadius) {
+      // the cutoff is decided on the light vector itself (the tile lists are conservative against exactly this sum)
+      const float d2 = fma_(wz, wz, fma_(wy, wy, wx * wx));
+      near[k] = clamp01_(fma_(d2, -kRadiusStepScale, kc.radius2_scaled));  // 1 iff dist^2 < radius^2
+    }
+    // dist^2 * 1e7 (kFrameScale), also with the cutoff: a radius beyond every light then gives the bytes of a call without one
+    dll[k] = fma_(ln[k], ln[k], fma_(lb[k], lb[k], lt[k] * lt[k]));
   }
-  rsq4(inv, dll);
-  float c[4], near[4], wd[4], ws[4], wp[4];
+  rsq4(inv, dll);  // sqrt(1e-7) / dist
+  float c[4], wu[4], wp[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    c[k] = ln[k] * inv[k];
-    if (kRadius) near[k] = clamp01_(fma_(dll[k], -kRadiusStepScale, kc.radius2_scaled));  // 1 iff dist^2 < radius^2
-  }
+  for (int k = 0; k < 4; ++k) c[k] = ln[k] * inv[k];
   bool skip = false;  // wave-uniform
   if (kProbe) {
     // deferred.comp:43,84 return 0 for l.n <= 1e-6.  When that holds for all four pairs of every lane, with every
     // cosine a number in [-2, -0] (as a signed integer the bit pattern of such a float is <= 0xC0000000; the
     // patterns of NaN, of -inf and of anything positive are greater), the step multiplier below is 0 and every other
     // factor is finite (positions, frames and 1/d are, or the cosine would not be a number of that size), so each of
-    // the twelve weights is +-0: the three remaining groups of transcendentals and the arithmetic between them are
+    // the eight weights is +-0: the three remaining groups of transcendentals and the arithmetic between them are
     // skipped and the weights set to 0.  The sums still take colour * 0 (a colour that is not finite makes that NaN,
     // as it does on the long way round).
     const int m01 = max(__float_as_int(c[0]), __float_as_int(c[1])), m23 = max(__float_as_int(c[2]), __float_as_int(c[3]));
@@ -215,7 +228,7 @@ __device__ __forceinline__ void shade4(Pixel& a, Pixel& b, const Light (&L)[kLig
   if (skip) {
     // as instructions of this branch: plain assignments are hoisted above the test, into every trip
 #pragma unroll
-    for (int k = 0; k < 4; ++k) asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0" : "=v"(wd[k]), "=v"(ws[k]), "=v"(wp[k]));
+    for (int k = 0; k < 4; ++k) asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0" : "=v"(wu[k]), "=v"(wp[k]));
   } else {
     float hh[4], dn[4], att[4], sh[4], qa[4], q[4];
 #pragma unroll
@@ -228,17 +241,18 @@ __device__ __forceinline__ void shade4(Pixel& a, Pixel& b, const Light (&L)[kLig
       const float hn2 = hn * hn;
       hh[k] = ht2 + hn2;
       dn[k] = fma_(s.a2, hn2, ht2);
-      att[k] = clamp01_((inv[k] * inv[k]) * kc.dist_floor);  // min(1/d^2, 1e7) * 1e-7
+      att[k] = clamp01_(inv[k] * inv[k]);  // min(1/d^2, 1e7) * 1e-7
     }
     sqrt4(sh, hh);
-    float kd[4], pvh[4], den[4], rden[4];
+    float akd[4], pvh[4], den[4], rden[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const Pixel& s = (kLights == 2 && (k & 1)) ? b : a;
       pvh[k] = pow5_(clamp01_(fma_(sh[k], -0.5f, 1.0f)));  // (1 - v.h)^5
       const float f90m1 = fma_(hh[k], s.rh, s.ebm1);
       const float pl = pow5_(clamp01_(1.0f - c[k]));
-      kd[k] = fma_(f90m1, pl, 1.0f) * fma_(f90m1, s.pv, 1.0f);
+      const float ga = fma_(f90m1, s.kapv, s.ka);          // A * FS(1, f90, v.n)
+      akd[k] = fma_(f90m1 * pl, ga, ga);                   // A * FS(v.n) * FS(l.n)   (deferred.comp:52-54)
       qa[k] = fma_(s.a2, c[k] * c[k], 1.0f);
     }
     sqrt4(q, qa);
@@ -247,14 +261,14 @@ __device__ __forceinline__ void shade4(Pixel& a, Pixel& b, const Light (&L)[kLig
     rcp4(rden, den);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+      const Pixel& s = (kLights == 2 && (k & 1)) ? b : a;
       // early-out of deferred.comp:43,84 as a multiplier: (c - 1e-6) * 2^100 is exact inside the FMA; its clamp
       // is 1 for every c > 1e-6 and 0 for c <= 1e-6 or NaN
       float ci = (c[k] * clamp01_(fma_(c[k], kc.step_scale, kc.step_bias))) * att[k];
       if (kRadius) ci *= near[k];
       const float ks0 = (hh[k] * hh[k]) * rden[k];
-      wd[k] = kd[k] * ci;
-      ws[k] = ks0 * ci;
-      wp[k] = ws[k] * pvh[k];
+      wu[k] = fma_(s.kb, ks0, akd[k]) * ci;  // what the albedo multiplies: A * diffuse + B * spec
+      wp[k] = ks0 * (ci * pvh[k]);           // spec * (1 - v.h)^5
     }
   }
   if (kRadius) {
@@ -268,15 +282,12 @@ __device__ __forceinline__ void shade4(Pixel& a, Pixel& b, const Light (&L)[kLig
   for (int k = 0; k < 4; ++k) {
     Pixel& s = (kLights == 2 && (k & 1)) ? b : a;
     const Light& l = L[kLights == 2 ? (k >> 1) : k];
-    s.ad[0] = fma_(l.cx, wd[k], s.ad[0]);
-    s.ad[1] = fma_(l.cy, wd[k], s.ad[1]);
-    s.ad[2] = fma_(l.cz, wd[k], s.ad[2]);
-    s.as0[0] = fma_(l.cx, ws[k], s.as0[0]);
-    s.as0[1] = fma_(l.cy, ws[k], s.as0[1]);
-    s.as0[2] = fma_(l.cz, ws[k], s.as0[2]);
-    s.as1[0] = fma_(l.cx, wp[k], s.as1[0]);
-    s.as1[1] = fma_(l.cy, wp[k], s.as1[1]);
-    s.as1[2] = fma_(l.cz, wp[k], s.as1[2]);
+    s.s1[0] = fma_(l.cx, wu[k], s.s1[0]);
+    s.s1[1] = fma_(l.cy, wu[k], s.s1[1]);
+    s.s1[2] = fma_(l.cz, wu[k], s.s1[2]);
+    s.s2[0] = fma_(l.cx, wp[k], s.s2[0]);
+    s.s2[1] = fma_(l.cy, wp[k], s.s2[1]);
+    s.s2[2] = fma_(l.cz, wp[k], s.s2[2]);
   }
   if (kProbe) fetch_next_col();
 }
@@ -287,6 +298,11 @@ __device__ __forceinline__ float clip_coord(uint32_t i, const ExactRcp& by_exten
 }
 
 __device__ __forceinline__ float unorm8(uint32_t word, int byte) { return (float)((word >> (8 * byte)) & 0xFFu) * (1.0f / 255.0f); }
+
+// Kspec * 1e7 = a2 / (PI (vn + sqrt(a2 vn^2 + 1))) * 1e7: the per-pixel factor of the specular term (file header).
+__device__ __forceinline__ float spec_scale(const Pixel& s) {
+  return (s.a2 * kInvDistFloor) * rcp_(kPi * (s.vn + sqrt_(fma_(s.a2, s.vn * s.vn, 1.0f))));
+}
 
 // deferred.comp:99-118: everything that does not depend on the light.
 __device__ __forceinline__ void setup_pixel(Pixel& s, const DeferredParams& p, float cx, float cy, float depth, uint32_t material,
@@ -335,37 +351,45 @@ __device__ __forceinline__ void setup_pixel(Pixel& s, const DeferredParams& p, f
   s.vb = fma_(vz, s.bz, fma_(vy, s.by, vx * s.bx));
   s.vn = fma_(vz, s.nz, fma_(vy, s.ny, vx * s.nx));
 
+  // the light loop works with the frame times kFrameScale
+  s.tx *= kFrameScale, s.ty *= kFrameScale, s.tz *= kFrameScale;
+  s.bx *= kFrameScale, s.by *= kFrameScale, s.bz *= kFrameScale;
+  s.nx *= kFrameScale, s.ny *= kFrameScale, s.nz *= kFrameScale;
+
   // :116 alpha = max(r*r, 0.0064)
   const float alpha = fmaxf(rough * rough, kAlphaFloor);
   s.a2 = alpha * alpha;
   s.rh = 0.5f * rough;
   s.ebm1 = fma_(0.5f, rough, -1.0f);
-  s.pv = pow5_(clamp01_(1.0f - s.vn));
+  // What multiplies a light's diffuse and specular weights per pixel, folded into the weights (the sums carry the
+  // 1e-7 of the distance floor, so the 1e7 goes in here): with albedo_k the channel's albedo and m the metalness,
+  //   colour_k = albedo_k * sum_j c_jk (A diffuse_j + B spec_j) + (Kspec - albedo_k B) * sum_j c_jk spec_j (1 - v.h)^5
+  // (deferred.comp:114-115: diffuseColor = albedo (1 - m), specularColor = albedo m; :36-38: F = Cs + (1 - Cs)(1 - v.h)^5)
+  const float metal = unorm8(material, 2);
+  const float ef = fma_(const_inv151(), rough, 1.0f - rough);  // mix(1, 1/1.51, r)
+  s.ka = (1.0f - metal) * ((kPi * kInvDistFloor) * ef);
+  s.kapv = s.ka * pow5_(clamp01_(1.0f - s.vn));
+  s.kb = metal * spec_scale(s);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) s.ad[k] = s.as0[k] = s.as1[k] = 0.0f;
+  for (int k = 0; k < 3; ++k) s.s1[k] = s.s2[k] = 0.0f;
   s.in_range = 0.0f;
 }
 
-// Combines the three light sums into the pixel colour (deferred.comp:107,114-115,127-128).  The
-// albedo and material words are decoded here, after the light loop, so that nothing of them occupies
-// registers during it.
+// Combines the two light sums into the pixel colour (deferred.comp:107,114-115,127-128; the formula is in the
+// file header).  The albedo word is decoded here, after the light loop, so that nothing of it occupies registers
+// during it.
 // `lit_by_any`: at least one light took part for this pixel (any light at all, or with the radius
 // cutoff one inside the radius).  A pixel whose normal or position is not a number (a cleared G-buffer
 // texel has normal 0: normalize(0)) then comes out NaN, as every term of deferred.comp:120-129 does
 // (rgba8 stores it as 0); with no light taking part it keeps its ambient colour.
 __device__ __forceinline__ void finish_pixel(const Pixel& s, uint32_t albedo, uint32_t material, bool lit_by_any, float out[3]) {
-  const float rough = unorm8(material, 1), metal = unorm8(material, 2);
   const bool front = s.vn > kEarlyOut;  // deferred.comp:43,84 (vDotN half of the early-out)
   const float unlit = (lit_by_any && !(s.vn == s.vn)) ? __builtin_nanf("") : 0.0f;
-  const float ef = fma_(const_inv151(), rough, 1.0f - rough);  // mix(1, 1/1.51, r)
-  const float kdiff = (kPi * kInvDistFloor) * ef;  // the light sums carry a factor 1e-7
-  const float kspec = (s.a2 * kInvDistFloor) * rcp_(kPi * (s.vn + sqrt_(fma_(s.a2, s.vn * s.vn, 1.0f))));
+  const float kspec = spec_scale(s);
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const float alb = unorm8(albedo, k);
-    const float cd = alb * (1.0f - metal);  // mix(albedo, 0, metal)
-    const float cs = alb * metal;           // mix(0, albedo, metal)
-    const float lit = fma_(cd * kdiff, s.ad[k], kspec * fma_(cs, s.as0[k], (1.0f - cs) * s.as1[k]));
+    const float lit = fma_(alb, s.s1[k], fma_(-alb, s.kb, kspec) * s.s2[k]);
     out[k] = fma_(kAmbient, alb, front ? lit : unlit);
   }
 }
@@ -466,7 +490,6 @@ __global__ __launch_bounds__(64 * kWaves, 4) void deferred_kernel(const Deferred
   // loop constants pinned in VGPRs: as SGPR or literal operands they would halve the issue rate of their users
   asm volatile("v_mov_b32 %0, %1" : "=v"(kc.step_scale) : "s"(kStepScale));
   asm volatile("v_mov_b32 %0, %1" : "=v"(kc.step_bias) : "s"(-kEarlyOut * kStepScale));
-  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.dist_floor) : "s"(kDistFloor));
   asm volatile("v_mov_b32 %0, %1" : "=v"(kc.radius2_scaled) : "s"(p.radius2 * kRadiusStepScale));
 
 #ifdef VKR_X_TIMES
@@ -696,7 +719,6 @@ __global__ __launch_bounds__(64, 4) void deferred_pixel_kernel(const DeferredPar
   LoopConsts kc;
   asm volatile("v_mov_b32 %0, %1" : "=v"(kc.step_scale) : "s"(kStepScale));
   asm volatile("v_mov_b32 %0, %1" : "=v"(kc.step_bias) : "s"(-kEarlyOut * kStepScale));
-  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.dist_floor) : "s"(kDistFloor));
   asm volatile("v_mov_b32 %0, %1" : "=v"(kc.radius2_scaled) : "s"(p.radius2 * kRadiusStepScale));
 
   const uint32_t x = blockIdx.x * 64u + t, y = blockIdx.y;
@@ -943,7 +965,6 @@ __device__ __forceinline__ void shade_strips(const DeferredParams& p, StripLds& 
   LoopConsts kc;
   asm volatile("v_mov_b32 %0, %1" : "=v"(kc.step_scale) : "s"(kStepScale));
   asm volatile("v_mov_b32 %0, %1" : "=v"(kc.step_bias) : "s"(-kEarlyOut * kStepScale));
-  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.dist_floor) : "s"(kDistFloor));
   asm volatile("v_mov_b32 %0, %1" : "=v"(kc.radius2_scaled) : "s"(p.radius2 * kRadiusStepScale));
 
   uint32_t class_end[kListClasses];
@@ -1168,7 +1189,6 @@ __device__ __forceinline__ void shade_deep_tiles(const DeferredParams& p, DeepLd
   LoopConsts kc;
   asm volatile("v_mov_b32 %0, %1" : "=v"(kc.step_scale) : "s"(kStepScale));
   asm volatile("v_mov_b32 %0, %1" : "=v"(kc.step_bias) : "s"(-kEarlyOut * kStepScale));
-  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.dist_floor) : "s"(kDistFloor));
   asm volatile("v_mov_b32 %0, %1" : "=v"(kc.radius2_scaled) : "s"(p.radius2 * kRadiusStepScale));
   const uint32_t n_tiles = p.tiles_x * p.tiles_y;
   const uint32_t q_end = p.lit_counters[kListClasses];
