@@ -339,7 +339,9 @@ def main():
         # communicator and raises in every surviving rank), and main() turns any exception into a non-zero exit
         from datetime import timedelta
         limit = timedelta(seconds=float(os.environ.get("VKR_BENCH_COLLECTIVE_TIMEOUT_S", "120")))
-        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        # 2 = on a collective's timeout the watchdog aborts the communicator and leaves the process alive: whatever waits
+        # for the collective returns, the next collective raises, and the sections below record that instead of dying
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "2")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index), timeout=limit)
         else:
@@ -424,7 +426,8 @@ def main():
     ach_flops = dflops / (kern_ms * 1e-3)
     ach_bytes = dbytes / (kern_ms * 1e-3)
 
-    result = {
+    result = RESULT
+    result.update({
         "metric": "shaded Gpixel/s at 4K x 256 lights (deferred.comp resolve)",
         "value": value,
         "unit": "Gpixel/s",
@@ -445,7 +448,8 @@ def main():
                      "kernel_ms": kern_ms, "kernel_ms_median": float(np.median(step_ms)), "kernel_ms_min": float(min(step_ms)),
                      "algorithmic_flops": dflops, "algorithmic_bytes": dbytes,
                      "hbm_achieved_GBps": ach_bytes / 1e9, "hbm_frac": ach_bytes / HBM_PEAK},
-    }
+    })
+    STATE["headline_done"] = True  # every rank is past the headline's last collective: what follows adds to the line
     if cold_ms is not None:
         result["roofline"]["kernel_ms_rotating_4_sets"] = cold_ms
 
@@ -478,13 +482,32 @@ def main():
                 "collective": "gather of rgba8 bands to rank 0 (RCCL), double-buffered: the gather of frame k overlaps the resolve of frame k+1",
                 "band_rows": [list(vdist.band_rows(height, world, r)) for r in range(world)], "verified": verified}
 
+    def sharded(name, fn):
+        """A sharded pipeline's line, or - when it raises (a collective that fails or times out, a HIP error) - the
+        error in its place and in the line's "errors"; once one has failed the others are not started (the
+        communicator may be gone), while the per-rank measurements go on."""
+        if STATE["sharded_failed"]:
+            return {"skipped": "an earlier sharded pipeline failed", "verified": None}
+        try:
+            if os.environ.get("VKR_BENCH_FAIL") == name:  # rehearsal of this path: VKR_BENCH_FAIL=band_sharded
+                raise RuntimeError("failure injected through VKR_BENCH_FAIL")
+            return fn()
+        except Exception as e:  # noqa: BLE001 - recorded, and the run goes on
+            import traceback
+            traceback.print_exc()
+            STATE["sharded_failed"] = True
+            result.setdefault("errors", {})[name] = f"{type(e).__name__}: {e}"
+            return {"error": f"{type(e).__name__}: {e}", "verified": None}
+
     if world > 1:
         frame = synth.deferred_case(W, H, L, config_index=1)  # the same frame on every rank
         gb.upload(frame["gbuf"])
         lights.upload(frame["lights"])
-        result["band_sharded"] = band_bench(gb, out, lights, L, frame["push"], 0, W, H)
+        result["band_sharded"] = sharded("band_sharded", lambda: band_bench(gb, out, lights, L, frame["push"], 0, W, H))
 
     # ---------------------------------------------------------------- cull
+    if os.environ.get("VKR_BENCH_FAIL") == "fatal":  # rehearsal of the exit handler: the line goes out with the headline
+        raise RuntimeError("failure injected through VKR_BENCH_FAIL")
     if not args.no_cull:
         N, M = args.instances, args.meshes
         # rotate through distinct input sets larger than the 256 MiB Infinity Cache in total
@@ -555,27 +578,31 @@ def main():
         if world > 1:
             # ONE scene split into instance ranges on mesh boundaries, one range per rank; the only exchange is the
             # gather of the per-mesh commands (20 bytes per mesh), the compacted lists stay where they were made
-            shared = synth.cull_case(N, M, config_index=2)
-            rpipe = vdist.RangeShardedCull(transport, shared["mesh_base"], N, vdist.hip_range_culler(vkr, ctx, shared, shared["planes"], 0))
-            cuts = rpipe.cuts
-            rt = vdist.timed_steps(transport, rpipe, K, WU, device_sync)
-            got = rpipe.commands()
-            verified = None
-            if rank == 0:  # the assembled command buffer against this rank's cull of the whole scene
-                whole = vkr.CullScene(ctx, shared["aabb_min"], shared["aabb_max"], shared["mesh_base"], shared["cmd_template"])
-                whole.run(shared["planes"], 0)
-                ctx.wait_idle()
-                verified = got == whole.results()["cmds"].tobytes()
-                del whole
-            del rpipe
-            cull["range_sharded"] = {"value": float(N) * K / rt / 1e9, "unit": "G instances/s", "ms_per_call": rt / K * 1e3, "scaling": "strong",
-                                     "collective": "gather of the per-mesh commands to rank 0 (RCCL), double-buffered",
-                                     "ranges": [[int(c[2]), int(c[3])] for c in cuts], "verified": verified}
+            def range_bench():
+                shared = synth.cull_case(N, M, config_index=2)
+                rpipe = vdist.RangeShardedCull(transport, shared["mesh_base"], N, vdist.hip_range_culler(vkr, ctx, shared, shared["planes"], 0))
+                cuts = rpipe.cuts
+                rt = vdist.timed_steps(transport, rpipe, K, WU, device_sync)
+                got = rpipe.commands()
+                verified = None
+                if rank == 0:  # the assembled command buffer against this rank's cull of the whole scene
+                    whole = vkr.CullScene(ctx, shared["aabb_min"], shared["aabb_max"], shared["mesh_base"], shared["cmd_template"])
+                    whole.run(shared["planes"], 0)
+                    ctx.wait_idle()
+                    verified = got == whole.results()["cmds"].tobytes()
+                    del whole
+                del rpipe
+                return {"value": float(N) * K / rt / 1e9, "unit": "G instances/s", "ms_per_call": rt / K * 1e3, "scaling": "strong",
+                        "collective": "gather of the per-mesh commands to rank 0 (RCCL), double-buffered",
+                        "ranges": [[int(c[2]), int(c[3])] for c in cuts], "verified": verified}
+
+            cull["range_sharded"] = sharded("cull.range_sharded", range_bench)
         result["cull"] = cull
 
     # ---------------------------------------------------------------- callers either side of the passes
     if not args.no_callers and not args.no_cull:
-        result["callers"] = bench_callers(ctx, vkr, synth, vdist, args, K, WU, rank, world, barrier, max_over_ranks, band_bench, pmc if default_workload else {})
+        result["callers"] = bench_callers(ctx, vkr, synth, vdist, args, K, WU, rank, world, barrier, max_over_ranks,
+                                          lambda *a: sharded("callers.tiled_resolve_8k.band_sharded", lambda: band_bench(*a)), pmc if default_workload else {})
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1)
     # Threads of the CPU legs: every CPU this process may run on.  os.cpu_count() reports the whole machine; the
@@ -638,13 +665,27 @@ def main():
         dist.destroy_process_group()
 
 
+# What main() has measured so far, and how far it got: the exit handler below prints the line with the headline in
+# it when a later section (the sharded pipelines, the callers) ends the run.
+RESULT: dict = {}
+STATE = {"headline_done": False, "sharded_failed": False}
+
+
 if __name__ == "__main__":
     try:
         main()
     except SystemExit:
         raise
-    except BaseException as e:  # a failed collective, a HIP error, a dead peer: say so and leave with a non-zero status
+    except BaseException as e:  # a failed collective, a HIP error, a dead peer: say so
         import traceback
         traceback.print_exc()
-        print(f"bench.py: rank {os.environ.get('RANK', '0')} failed: {e}", file=sys.stderr, flush=True)
+        rank_ = os.environ.get("RANK", "0")
+        print(f"bench.py: rank {rank_} failed: {e}", file=sys.stderr, flush=True)
+        if STATE["headline_done"] and not isinstance(e, KeyboardInterrupt):
+            # the headline was measured on every rank (its last collective is behind them): the line goes out with what
+            # there is and with the failure in it, and the run counts as one that produced its metric
+            if rank_ == "0":
+                RESULT.setdefault("errors", {})["fatal"] = f"{type(e).__name__}: {e}"
+                print(json.dumps(RESULT), flush=True)
+            os._exit(0)
         os._exit(1)  # not sys.exit: a hung communicator's destructor must not get the chance to block the exit
