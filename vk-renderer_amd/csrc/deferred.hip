@@ -809,6 +809,250 @@ __global__ __launch_bounds__(64, 4) void deferred_pixel_kernel(const DeferredPar
   }
 }
 
+// ------------------------------------------------------------------ whole table, each pixel walks only its own lights
+// deferred.comp:43,84 return 0 for a light with l.n <= 1e-6: in a frame whose normals face all ways (the headline's
+// synthetic G-buffer) two thirds of the (pixel, light) evaluations end there, but hardly ever for all 64 pixels of a
+// wave at once, so the wave-uniform tests of the kernels above find nothing to skip.  This kernel gives every pixel
+// its own list: a bit per light, set unless a cheap and provably one-sided test says the light is behind the
+// pixel's surface; each lane then walks the set bits of its own mask, four lights per trip, fetching its lights'
+// records from LDS by its own indices.  A skipped light is one whose weights the long way round would be exactly
+// +-0 and whose colour is finite, so the sums - taken in table order either way - come out bit for bit the same.
+//
+// The test: with n' the scaled shading normal, l.n' - p.n' + margin < 0, three multiply-adds per (pixel, light)
+// on the staged light position (no light vector, no rsq), its sign shifted into the mask by one v_alignbit.  The
+// margin, 2^-20 * kFrameScale * (|p|_1 + largest |l|_1 of the table), exceeds the rounding of this sum and of the
+// long way's (l - p).n' together (each below 2^-22 * kFrameScale * (|l|_1 + |p|_1)), so a set sign bit means the long
+// way's l.n' is negative, not tiny, and its cosine a number in [-1, -0].  Lights that are not finite, or beyond 1e15
+// (the long way's sums overflow there), are walked by every pixel (s_force), pixels beyond 1e15 walk every light, and
+// pixels no light can change (v.n <= 1e-6 or not a number) walk none.
+//
+// Lanes that walk lists of different lengths wait for the longest, and the lengths differ widely (a pixel facing
+// the bulk of the lights passes 70 % of them, one facing away 10 %), so the pixels of a 32 x 32 tile are first
+// counted (the same test, bits only counted), sorted by count (counting sort over 64 buckets in LDS), and dealt
+// out in that order: a wave shades four batches of 64 pixels of like counts, taken so that the four waves of the
+// workgroup end up with like totals (batches w, 7 - w, 8 + w, 15 - w of the order).  One workgroup per tile, at
+// most kWalkLights lights (one LDS chunk; longer tables go to the kernels above).
+constexpr uint32_t kWalkLights = 256;
+constexpr uint32_t kWalkStride = 7;   // dwords per staged record (px py pz cx cy cz, one unused): 7 is coprime with the 32 banks
+constexpr float kWalkMargin = 0x1p-20f * kFrameScale;
+constexpr float kWalkFar = 1e15f;
+
+// The sign of `v` shifted into `mask` from below: light j of a block of 32 ends up in bit 31 - j.
+__device__ __forceinline__ uint32_t push_sign(uint32_t mask, float v) { return __builtin_amdgcn_alignbit(mask, __float_as_uint(v), 31u); }
+
+template <int kOutMode>
+__global__ __launch_bounds__(256, 4) void deferred_walk_kernel(const DeferredParams p) {
+  __shared__ float s_rec[(kWalkLights + 1u) * kWalkStride];  // + the black light, which lanes whose list has ended walk
+  __shared__ uint32_t s_mask[4][kWalkLights / 32u][64];      // per wave: word w of lane l's list
+  __shared__ uint32_t s_force[kWalkLights / 32u];
+  __shared__ uint32_t s_hist[64];
+  __shared__ uint16_t s_order[1024];
+  __shared__ uint32_t s_out[1024];  // 8-bit results by pixel (row << 5 | column within the tile)
+  __shared__ uint32_t s_lmax;
+  constexpr bool kIs8Bit = kOutMode == kOutRgba8 || kOutMode == kOutBgra8;
+  const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+  const uint32_t L = p.light_count;  // 1 .. kWalkLights
+  const uint32_t words = (L + 31u) / 32u;
+  const uint32_t tile_x = blockIdx.x, tile_y = blockIdx.y;
+
+  // ---- the table into LDS; which lights every pixel must walk; the largest |l|_1 of the others
+  if (t == 0u) s_lmax = 0u;
+  if (t < 64u) s_hist[t] = 0u;
+  __syncthreads();
+  {
+    float4 lp = make_float4(0.0f, 0.0f, 1e18f, 0.0f), lc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    bool forced = false;
+    if (t < L) {
+      const float4* __restrict__ lights = reinterpret_cast<const float4*>(p.lights);
+      lp = lights[3u * t];
+      lc = lights[3u * t + 1u];
+      const float l1 = (fabsf(lp.x) + fabsf(lp.y)) + fabsf(lp.z), c1 = (fabsf(lc.x) + fabsf(lc.y)) + fabsf(lc.z);
+      forced = !(l1 < kWalkFar) || !(c1 < INFINITY);  // also true for NaN
+      if (!forced) atomicMax(&s_lmax, __float_as_uint(l1));
+    }
+    float* r = s_rec + t * kWalkStride;
+    r[0] = lp.x, r[1] = lp.y, r[2] = lp.z, r[3] = lc.x, r[4] = lc.y, r[5] = lc.z;
+    if (t == 0u) {
+      float* b = s_rec + kWalkLights * kWalkStride;
+      b[0] = 0.0f, b[1] = 0.0f, b[2] = 1e18f, b[3] = 0.0f, b[4] = 0.0f, b[5] = 0.0f;
+    }
+    const uint64_t f = __ballot(forced);
+    if (lane == 0u) {
+      s_force[2u * wave] = __brev((uint32_t)f);
+      s_force[2u * wave + 1u] = __brev((uint32_t)(f >> 32));
+    }
+  }
+  __syncthreads();
+  const float lmax = __uint_as_float(s_lmax);
+  // bits of word w that stand for lights of the table
+  auto valid_bits = [&](uint32_t w) -> uint32_t { return (w + 1u) * 32u <= L ? 0xFFFFFFFFu : (w * 32u < L ? 0xFFFFFFFFu << (32u - (L & 31u)) : 0u); };
+
+  const ExactRcp by_width = exact_rcp((float)p.width), by_height = exact_rcp((float)p.full_height);
+
+  // A pixel's side of the test: the scaled normal and cst = margin - p.n'; kind: 0 walks none, 1 tests, 2 walks all.
+  struct Side {
+    float nx, ny, nz, cst;
+    uint32_t kind;
+  };
+  auto side_of = [&](const Pixel& s, bool in_image) {
+    Side d;
+    d.nx = s.nx, d.ny = s.ny, d.nz = s.nz;
+    const float p1 = (fabsf(s.px) + fabsf(s.py)) + fabsf(s.pz);
+    const float pn = fma_(s.pz, s.nz, fma_(s.py, s.ny, s.px * s.nx));
+    d.cst = fma_(kWalkMargin, p1 + lmax, 1e-15f) - pn;
+    d.kind = !(in_image && s.vn > kEarlyOut) ? 0u : (p1 < kWalkFar ? 1u : 2u);
+    return d;
+  };
+  // word w of a pixel's list from the signs shifted in for its 32 lights (`raw`, the last word's lights in its top bits)
+  auto list_word = [&](uint32_t raw, uint32_t w, const Side& d) -> uint32_t {
+    const uint32_t tested = (~raw | s_force[w]) & valid_bits(w);
+    return d.kind == 0u ? 0u : (d.kind == 1u ? tested : valid_bits(w));
+  };
+
+  // ---- how many lights each pixel of the tile walks; lane t counts for the four pixels 4*(t&7) .. +3 of row t>>3
+  {
+    const uint32_t x0 = tile_x * 32u + (t & 7u) * 4u, y = tile_y * 32u + (t >> 3);
+    const bool row_in = y < p.height && x0 < p.width;
+    const uint32_t lx = row_in ? x0 : tile_x * 32u, ly = row_in ? y : tile_y * 32u;  // in bounds by construction
+    const float4 dep4 = *reinterpret_cast<const float4*>(p.depth + (size_t)ly * p.pitch_depth + (size_t)lx * 4u);
+    const uint4 mat4 = *reinterpret_cast<const uint4*>(p.material + (size_t)ly * p.pitch_material + (size_t)lx * 4u);
+    const uint4 nrmA = *reinterpret_cast<const uint4*>(p.normal + (size_t)ly * p.pitch_normal + (size_t)lx * 8u);
+    const uint4 nrmB = *reinterpret_cast<const uint4*>(p.normal + (size_t)ly * p.pitch_normal + (size_t)lx * 8u + 16u);
+    const float dep[4] = {dep4.x, dep4.y, dep4.z, dep4.w};
+    const uint32_t mat[4] = {mat4.x, mat4.y, mat4.z, mat4.w};
+    const uint32_t nlo[4] = {nrmA.x, nrmA.z, nrmB.x, nrmB.z}, nhi[4] = {nrmA.y, nrmA.w, nrmB.y, nrmB.w};
+    const float cy = clip_coord(ly + p.row_offset, by_height);
+    Side d[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      Pixel s;
+      setup_pixel(s, p, clip_coord(lx + (uint32_t)i, by_width), cy, dep[i], mat[i], nlo[i], nhi[i]);
+      d[i] = side_of(s, row_in && x0 + (uint32_t)i < p.width);
+    }
+    uint32_t count[4] = {0u, 0u, 0u, 0u};
+    for (uint32_t w = 0; w < words; ++w) {
+      const uint32_t n = min(32u, L - w * 32u);
+      uint32_t raw[4] = {0u, 0u, 0u, 0u};
+      const float* r = s_rec + w * 32u * kWalkStride;
+      for (uint32_t j = 0; j < n; ++j, r += kWalkStride) {
+        const float qx = r[0], qy = r[1], qz = r[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) raw[i] = push_sign(raw[i], fma_(qz, d[i].nz, fma_(qy, d[i].ny, fma_(qx, d[i].nx, d[i].cst))));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) count[i] += __popc(list_word(raw[i] << (32u - n), w, d[i]));
+    }
+    // counting sort by count / 4 (64 buckets; equal counts stay together, their order among themselves is arbitrary
+    // and changes nothing: a pixel's result does not depend on the lane that shades it)
+    uint32_t bucket[4], within[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bucket[i] = min(count[i], 255u) >> 2;
+      within[i] = atomicAdd(&s_hist[bucket[i]], 1u);
+    }
+    __syncthreads();
+    if (wave == 0u) {
+      const uint32_t mine = s_hist[lane];
+      uint32_t incl = mine;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off);
+        if (lane >= (uint32_t)off) incl += up;
+      }
+      s_hist[lane] = incl - mine;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s_order[s_hist[bucket[i]] + within[i]] = (uint16_t)((t >> 3) * 32u + (t & 7u) * 4u + (uint32_t)i);
+    __syncthreads();
+  }
+
+  LoopConsts kc;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.step_scale) : "s"(kStepScale));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(kc.step_bias) : "s"(-kEarlyOut * kStepScale));
+  kc.radius2_scaled = 0.0f;
+  Probe probe{0u};
+
+  // ---- four batches of 64 pixels per wave
+#pragma unroll 1
+  for (uint32_t k = 0; k < 4u; ++k) {
+    const uint32_t batch = (k & 1u) ? 4u * k + 3u - wave : 4u * k + wave;
+    const uint32_t id = s_order[64u * batch + lane];
+    const uint32_t x = tile_x * 32u + (id & 31u), y = tile_y * 32u + (id >> 5);
+    const bool inside = x < p.width && y < p.height;
+    const uint32_t lx = inside ? x : tile_x * 32u, ly = inside ? y : tile_y * 32u;
+    const uint32_t alb = *reinterpret_cast<const uint32_t*>(p.albedo + (size_t)ly * p.pitch_albedo + (size_t)lx * 4u);
+    const uint32_t mat = *reinterpret_cast<const uint32_t*>(p.material + (size_t)ly * p.pitch_material + (size_t)lx * 4u);
+    const float dep = *reinterpret_cast<const float*>(p.depth + (size_t)ly * p.pitch_depth + (size_t)lx * 4u);
+    const uint2 nrm = *reinterpret_cast<const uint2*>(p.normal + (size_t)ly * p.pitch_normal + (size_t)lx * 8u);
+    Pixel s;
+    setup_pixel(s, p, clip_coord(lx, by_width), clip_coord(ly + p.row_offset, by_height), dep, mat, nrm.x, nrm.y);
+    {
+      const Side d = side_of(s, inside);
+      for (uint32_t w = 0; w < words; ++w) {
+        const uint32_t n = min(32u, L - w * 32u);
+        uint32_t raw = 0u;
+        const float* r = s_rec + w * 32u * kWalkStride;
+        for (uint32_t j = 0; j < n; ++j, r += kWalkStride) raw = push_sign(raw, fma_(r[2], d.nz, fma_(r[1], d.ny, fma_(r[0], d.nx, d.cst))));
+        s_mask[wave][w][lane] = list_word(raw << (32u - n), w, d);
+      }
+    }
+    // one wave: its LDS accesses execute in program order; only the compiler has to be kept from reordering them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    uint32_t cur = 0u, wi = 0u;  // the word being walked (bits of lights not yet taken) and the index of the next one
+    for (;;) {
+      uint32_t at[4];  // dword offsets of this trip's four records
+      bool any = false;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (cur == 0u && wi < words) {
+          cur = s_mask[wave][wi][lane];
+          ++wi;
+        }
+        const bool has = cur != 0u;
+        const uint32_t pos = (uint32_t)__clz((int)cur);  // 32 for 0
+        at[e] = has ? ((wi - 1u) * 32u + pos) * kWalkStride : kWalkLights * kWalkStride;
+        cur = has ? (cur & ~(0x80000000u >> (pos & 31u))) : 0u;
+        any = any || has;
+      }
+      const bool more = cur != 0u || wi < words;
+      if (__ballot(any || more) == 0ull) break;
+      Light four[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* r = s_rec + at[e];
+        four[e] = Light{r[0], r[1], r[2], r[3], r[4], r[5]};
+      }
+      shade4<false, false>(s, s, four, kc, probe, [] {}, [] {});
+    }
+    float rgb[3];
+    finish_pixel(s, alb, mat, true, rgb);
+    if (kIs8Bit) {
+      s_out[id] = pack_unorm8<kOutMode>(rgb);
+    } else if (inside) {
+      uint8_t* orow = p.out + (size_t)y * p.pitch_out;
+      if (kOutMode == kOutRgba16f)
+        reinterpret_cast<uint2*>(orow)[x] = half_texel(rgb[0], rgb[1], rgb[2]);
+      else
+        reinterpret_cast<float4*>(orow)[x] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (kIs8Bit) {
+    __syncthreads();
+    const uint32_t x0 = tile_x * 32u + (t & 7u) * 4u, y = tile_y * 32u + (t >> 3);
+    if (y < p.height && x0 < p.width) {
+      const uint32_t at = (t >> 3) * 32u + (t & 7u) * 4u;
+      const uint32_t packed[4] = {s_out[at], s_out[at + 1u], s_out[at + 2u], s_out[at + 3u]};
+      store_rgba8x4(p.out + (size_t)y * p.pitch_out, x0, min(4u, p.width - x0), packed);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ bounds of a tile's pixel positions
 // Wave-uniform bounds of a tile's pixel positions: a padded world-space box and the four side faces of the
 // tile's view pyramid (outward unit normal + offset), plus reach = radius + pad.
@@ -1876,6 +2120,14 @@ constexpr uint32_t kListMaxLights = 65536;        // list entries are 16-bit lig
 #endif
 constexpr uint32_t kFineRounds = VKR_X_FINE_ROUNDS;               // whole-table launches of fewer rounds of four-wave workgroups than this shade one pixel per lane
 
+#ifndef VKR_X_WALK_FINE
+#define VKR_X_WALK_FINE 0
+#endif
+#ifndef VKR_X_WALK_MIN
+#define VKR_X_WALK_MIN 1
+#endif
+constexpr uint32_t kWalkMinLights = VKR_X_WALK_MIN;
+
 template <int kOutMode>
 hipError_t launch_mode(const DeferredParams& p, const TileListOut* lists, uint32_t cu_count, bool deep_tiles_expected, hipStream_t stream) {
   const dim3 grid((p.width + 31u) / 32u, (p.height + 31u) / 32u, 1u);
@@ -1883,7 +2135,10 @@ hipError_t launch_mode(const DeferredParams& p, const TileListOut* lists, uint32
   // fewer than kFineRounds rounds of four-wave workgroups (four of them fit a CU): one pixel per lane, single-wave workgroups
   const bool fine = (p.flags & 4u) == 0u && (uint64_t)grid.x * grid.y < (uint64_t)kFineRounds * 4u * cu_count;
   const dim3 fine_grid((p.width + 63u) / 64u, p.height, 1u);  // one wave per 64 pixels of a row
-  if (lists == nullptr) {
+  const bool walk = !radius && (p.flags & 4u) == 0u && p.light_count >= kWalkMinLights && p.light_count <= kWalkLights && !(fine && !VKR_X_WALK_FINE);
+  if (lists == nullptr && walk) {
+    hipLaunchKernelGGL((deferred_walk_kernel<kOutMode>), grid, dim3(256), 0, stream, p);
+  } else if (lists == nullptr) {
     if (!radius && !fine) hipLaunchKernelGGL((deferred_kernel<kOutMode, false, 4>), grid, dim3(256), 0, stream, p);
     if (!radius && fine) hipLaunchKernelGGL((deferred_pixel_kernel<kOutMode, false>), fine_grid, dim3(64), 0, stream, p);
     if (radius && !fine) hipLaunchKernelGGL((deferred_kernel<kOutMode, true, 4>), grid, dim3(256), 0, stream, p);
