@@ -819,151 +819,202 @@ __global__ __launch_bounds__(64, 4) void deferred_pixel_kernel(const DeferredPar
 // +-0 and whose colour is finite, so the sums - taken in table order either way - come out bit for bit the same.
 //
 // The test: with n' the scaled shading normal, l.n' - p.n' + margin < 0, three multiply-adds per (pixel, light)
-// on the staged light position (no light vector, no rsq), its sign shifted into the mask by one v_alignbit.  The
+// on the light's position (no light vector, no rsq), its sign shifted into the mask by one v_alignbit.  The
 // margin, 2^-20 * kFrameScale * (|p|_1 + largest |l|_1 of the table), exceeds the rounding of this sum and of the
 // long way's (l - p).n' together (each below 2^-22 * kFrameScale * (|l|_1 + |p|_1)), so a set sign bit means the long
 // way's l.n' is negative, not tiny, and its cosine a number in [-1, -0].  Lights that are not finite, or beyond 1e15
-// (the long way's sums overflow there), are walked by every pixel (s_force), pixels beyond 1e15 walk every light, and
-// pixels no light can change (v.n <= 1e-6 or not a number) walk none.
+// (the long way's sums overflow there), are walked by every pixel (force), pixels beyond 1e15 walk every light, and
+// pixels no light can change (v.n <= 1e-6 or not a number) walk none.  The positions come through scalar loads (the
+// index is uniform): as LDS reads they would be 12 bytes per lane and light for four instructions' worth of work, three
+// times what a CU's LDS delivers.
 //
 // Lanes that walk lists of different lengths wait for the longest, and the lengths differ widely (a pixel facing
-// the bulk of the lights passes 70 % of them, one facing away 10 %), so the pixels of a 32 x 32 tile are first
-// counted (the same test, bits only counted), sorted by count (counting sort over 64 buckets in LDS), and dealt
-// out in that order: a wave shades four batches of 64 pixels of like counts, taken so that the four waves of the
-// workgroup end up with like totals (batches w, 7 - w, 8 + w, 15 - w of the order).  One workgroup per tile, at
-// most kWalkLights lights (one LDS chunk; longer tables go to the kernels above).
+// the bulk of the lights passes 70 % of them, one facing away 10 %), so the pixels of a tile are sorted by list
+// length (counting sort over 64 buckets in LDS) and dealt out in that order: a wave shades batches of 64 pixels of
+// like lengths, taken so that the four waves of the workgroup end up with like totals (batches w, 7 - w, 8 + w,
+// 15 - w of the order).  Unsorted the kernel is slower than the loops that evaluate everything (2.76 against 2.25 ms).
+// One workgroup per tile of 32 x kWalkRows pixels, at most kWalkLights lights (one LDS chunk; longer tables go to the
+// kernels above).
 constexpr uint32_t kWalkLights = 256;
+constexpr uint32_t kWalkWords = kWalkLights / 32u;
 constexpr uint32_t kWalkStride = 7;   // dwords per staged record (px py pz cx cy cz, one unused): 7 is coprime with the 32 banks
 constexpr float kWalkMargin = 0x1p-20f * kFrameScale;
 constexpr float kWalkFar = 1e15f;
+#ifndef VKR_X_WALK_ROWS
+#define VKR_X_WALK_ROWS 16
+#endif
+constexpr uint32_t kWalkRows = VKR_X_WALK_ROWS;          // 16 or 32
+constexpr uint32_t kWalkPixels = 32u * kWalkRows;        // per tile
+constexpr uint32_t kWalkHome = kWalkPixels / 256u;       // consecutive pixels of a row that a lane prepares
+
+// The first 16 bytes of eight consecutive 48-byte light records at a wave-uniform address, through the scalar cache
+// into scalar registers: one address, eight immediate offsets, one wait.  (Written as indexed loads the compiler
+// splits each record into three one-dword loads with an address computation each and waits after every second one.)
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void scalar_load_8_records(const float4* base, v4f (&q)[8]) {
+  asm volatile(
+      "s_load_dwordx4 %0, %8, 0x0\n\t"
+      "s_load_dwordx4 %1, %8, 0x30\n\t"
+      "s_load_dwordx4 %2, %8, 0x60\n\t"
+      "s_load_dwordx4 %3, %8, 0x90\n\t"
+      "s_load_dwordx4 %4, %8, 0xc0\n\t"
+      "s_load_dwordx4 %5, %8, 0xf0\n\t"
+      "s_load_dwordx4 %6, %8, 0x120\n\t"
+      "s_load_dwordx4 %7, %8, 0x150\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(q[0]), "=&s"(q[1]), "=&s"(q[2]), "=&s"(q[3]), "=&s"(q[4]), "=&s"(q[5]), "=&s"(q[6]), "=&s"(q[7])
+      : "s"(base)
+      : "memory");
+}
 
 // The sign of `v` shifted into `mask` from below: light j of a block of 32 ends up in bit 31 - j.
 __device__ __forceinline__ uint32_t push_sign(uint32_t mask, float v) { return __builtin_amdgcn_alignbit(mask, __float_as_uint(v), 31u); }
 
+struct WalkLds {
+  float rec[(kWalkLights + 1u) * kWalkStride];  // first, so that a record's dwords are immediate offsets from its address; + the black light, which lanes whose list has ended walk
+  uint32_t mask[kWalkWords][kWalkPixels];       // word w of pixel id's list
+  uint32_t force[kWalkWords];
+  uint32_t hist[64];
+  uint32_t lmax;
+  uint32_t out[kWalkPixels];                    // 8-bit results by pixel (row << 5 | column within the tile)
+  uint16_t order[kWalkPixels];
+};
+
 template <int kOutMode>
 __global__ __launch_bounds__(256, 4) void deferred_walk_kernel(const DeferredParams p) {
-  __shared__ float s_rec[(kWalkLights + 1u) * kWalkStride];  // + the black light, which lanes whose list has ended walk
-  __shared__ uint32_t s_mask[4][kWalkLights / 32u][64];      // per wave: word w of lane l's list
-  __shared__ uint32_t s_force[kWalkLights / 32u];
-  __shared__ uint32_t s_hist[64];
-  __shared__ uint16_t s_order[1024];
-  __shared__ uint32_t s_out[1024];  // 8-bit results by pixel (row << 5 | column within the tile)
-  __shared__ uint32_t s_lmax;
+  __shared__ WalkLds lds;
   constexpr bool kIs8Bit = kOutMode == kOutRgba8 || kOutMode == kOutBgra8;
   const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
   const uint32_t L = p.light_count;  // 1 .. kWalkLights
   const uint32_t words = (L + 31u) / 32u;
   const uint32_t tile_x = blockIdx.x, tile_y = blockIdx.y;
+  const float4* __restrict__ lights = reinterpret_cast<const float4*>(p.lights);
 
   // ---- the table into LDS; which lights every pixel must walk; the largest |l|_1 of the others
-  if (t == 0u) s_lmax = 0u;
-  if (t < 64u) s_hist[t] = 0u;
+  if (t == 0u) lds.lmax = 0u;
+  if (t < 64u) lds.hist[t] = 0u;
   __syncthreads();
   {
     float4 lp = make_float4(0.0f, 0.0f, 1e18f, 0.0f), lc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     bool forced = false;
     if (t < L) {
-      const float4* __restrict__ lights = reinterpret_cast<const float4*>(p.lights);
       lp = lights[3u * t];
       lc = lights[3u * t + 1u];
       const float l1 = (fabsf(lp.x) + fabsf(lp.y)) + fabsf(lp.z), c1 = (fabsf(lc.x) + fabsf(lc.y)) + fabsf(lc.z);
       forced = !(l1 < kWalkFar) || !(c1 < INFINITY);  // also true for NaN
-      if (!forced) atomicMax(&s_lmax, __float_as_uint(l1));
+      if (!forced) atomicMax(&lds.lmax, __float_as_uint(l1));
     }
-    float* r = s_rec + t * kWalkStride;
+    float* r = lds.rec + t * kWalkStride;
     r[0] = lp.x, r[1] = lp.y, r[2] = lp.z, r[3] = lc.x, r[4] = lc.y, r[5] = lc.z;
     if (t == 0u) {
-      float* b = s_rec + kWalkLights * kWalkStride;
+      float* b = lds.rec + kWalkLights * kWalkStride;
       b[0] = 0.0f, b[1] = 0.0f, b[2] = 1e18f, b[3] = 0.0f, b[4] = 0.0f, b[5] = 0.0f;
     }
     const uint64_t f = __ballot(forced);
     if (lane == 0u) {
-      s_force[2u * wave] = __brev((uint32_t)f);
-      s_force[2u * wave + 1u] = __brev((uint32_t)(f >> 32));
+      lds.force[2u * wave] = __brev((uint32_t)f);
+      lds.force[2u * wave + 1u] = __brev((uint32_t)(f >> 32));
     }
   }
   __syncthreads();
-  const float lmax = __uint_as_float(s_lmax);
+  const float lmax = __uint_as_float(lds.lmax);
   // bits of word w that stand for lights of the table
   auto valid_bits = [&](uint32_t w) -> uint32_t { return (w + 1u) * 32u <= L ? 0xFFFFFFFFu : (w * 32u < L ? 0xFFFFFFFFu << (32u - (L & 31u)) : 0u); };
 
   const ExactRcp by_width = exact_rcp((float)p.width), by_height = exact_rcp((float)p.full_height);
 
-  // A pixel's side of the test: the scaled normal and cst = margin - p.n'; kind: 0 walks none, 1 tests, 2 walks all.
-  struct Side {
-    float nx, ny, nz, cst;
-    uint32_t kind;
-  };
-  auto side_of = [&](const Pixel& s, bool in_image) {
-    Side d;
-    d.nx = s.nx, d.ny = s.ny, d.nz = s.nz;
-    const float p1 = (fabsf(s.px) + fabsf(s.py)) + fabsf(s.pz);
-    const float pn = fma_(s.pz, s.nz, fma_(s.py, s.ny, s.px * s.nx));
-    d.cst = fma_(kWalkMargin, p1 + lmax, 1e-15f) - pn;
-    d.kind = !(in_image && s.vn > kEarlyOut) ? 0u : (p1 < kWalkFar ? 1u : 2u);
-    return d;
-  };
-  // word w of a pixel's list from the signs shifted in for its 32 lights (`raw`, the last word's lights in its top bits)
-  auto list_word = [&](uint32_t raw, uint32_t w, const Side& d) -> uint32_t {
-    const uint32_t tested = (~raw | s_force[w]) & valid_bits(w);
-    return d.kind == 0u ? 0u : (d.kind == 1u ? tested : valid_bits(w));
-  };
-
-  // ---- how many lights each pixel of the tile walks; lane t counts for the four pixels 4*(t&7) .. +3 of row t>>3
+  // ---- every pixel's list; lane t prepares the kWalkHome consecutive pixels of its row
   {
-    const uint32_t x0 = tile_x * 32u + (t & 7u) * 4u, y = tile_y * 32u + (t >> 3);
+    constexpr uint32_t kLanesPerRow = 32u / kWalkHome;
+    const uint32_t xl = (t % kLanesPerRow) * kWalkHome, yl = t / kLanesPerRow;
+    const uint32_t x0 = tile_x * 32u + xl, y = tile_y * kWalkRows + yl;
     const bool row_in = y < p.height && x0 < p.width;
-    const uint32_t lx = row_in ? x0 : tile_x * 32u, ly = row_in ? y : tile_y * 32u;  // in bounds by construction
-    const float4 dep4 = *reinterpret_cast<const float4*>(p.depth + (size_t)ly * p.pitch_depth + (size_t)lx * 4u);
-    const uint4 mat4 = *reinterpret_cast<const uint4*>(p.material + (size_t)ly * p.pitch_material + (size_t)lx * 4u);
-    const uint4 nrmA = *reinterpret_cast<const uint4*>(p.normal + (size_t)ly * p.pitch_normal + (size_t)lx * 8u);
-    const uint4 nrmB = *reinterpret_cast<const uint4*>(p.normal + (size_t)ly * p.pitch_normal + (size_t)lx * 8u + 16u);
-    const float dep[4] = {dep4.x, dep4.y, dep4.z, dep4.w};
-    const uint32_t mat[4] = {mat4.x, mat4.y, mat4.z, mat4.w};
-    const uint32_t nlo[4] = {nrmA.x, nrmA.z, nrmB.x, nrmB.z}, nhi[4] = {nrmA.y, nrmA.w, nrmB.y, nrmB.w};
+    const uint32_t lx = row_in ? x0 : tile_x * 32u, ly = row_in ? y : tile_y * kWalkRows;  // in bounds by construction
     const float cy = clip_coord(ly + p.row_offset, by_height);
-    Side d[4];
+    // a pixel's side of the test: the scaled normal and cst = margin - p.n'; kind: 0 walks none, 1 tests, 2 walks all
+    float nx[kWalkHome], ny[kWalkHome], nz[kWalkHome], cst[kWalkHome];
+    uint32_t kind[kWalkHome], count[kWalkHome];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (uint32_t i = 0; i < kWalkHome; ++i) {
+      const uint32_t xi = min(lx + i, p.width - 1u);
+      const float dep = *reinterpret_cast<const float*>(p.depth + (size_t)ly * p.pitch_depth + (size_t)xi * 4u);
+      const uint32_t mat = *reinterpret_cast<const uint32_t*>(p.material + (size_t)ly * p.pitch_material + (size_t)xi * 4u);
+      const uint2 nrm = *reinterpret_cast<const uint2*>(p.normal + (size_t)ly * p.pitch_normal + (size_t)xi * 8u);
       Pixel s;
-      setup_pixel(s, p, clip_coord(lx + (uint32_t)i, by_width), cy, dep[i], mat[i], nlo[i], nhi[i]);
-      d[i] = side_of(s, row_in && x0 + (uint32_t)i < p.width);
+      setup_pixel(s, p, clip_coord(xi, by_width), cy, dep, mat, nrm.x, nrm.y);
+      nx[i] = s.nx, ny[i] = s.ny, nz[i] = s.nz;
+      const float p1 = (fabsf(s.px) + fabsf(s.py)) + fabsf(s.pz);
+      const float pn = fma_(s.pz, s.nz, fma_(s.py, s.ny, s.px * s.nx));
+      cst[i] = fma_(kWalkMargin, p1 + lmax, 1e-15f) - pn;
+      const bool in_image = row_in && x0 + i < p.width;
+      kind[i] = !(in_image && s.vn > kEarlyOut) ? 0u : (p1 < kWalkFar ? 1u : 2u);
+      count[i] = 0u;
     }
-    uint32_t count[4] = {0u, 0u, 0u, 0u};
     for (uint32_t w = 0; w < words; ++w) {
-      const uint32_t n = min(32u, L - w * 32u);
-      uint32_t raw[4] = {0u, 0u, 0u, 0u};
-      const float* r = s_rec + w * 32u * kWalkStride;
-      for (uint32_t j = 0; j < n; ++j, r += kWalkStride) {
-        const float qx = r[0], qy = r[1], qz = r[2];
+      uint32_t raw[kWalkHome];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) raw[i] = push_sign(raw[i], fma_(qz, d[i].nz, fma_(qy, d[i].ny, fma_(qx, d[i].nx, d[i].cst))));
+      for (uint32_t i = 0; i < kWalkHome; ++i) raw[i] = 0u;
+      // always 32 lights (beyond the table's end its last light again: those bits are masked off below), eight
+      // positions requested at a time so that their round trips overlap; a whole block of eight is one address and
+      // eight immediate offsets
+      for (uint32_t j0 = 0; j0 < 32u; j0 += 8u) {
+        float qx[8], qy[8], qz[8];
+        const uint32_t first = w * 32u + j0;
+        if (first + 8u <= L) {
+          v4f q[8];
+          scalar_load_8_records(lights + 3u * first, q);
+#pragma unroll
+          for (uint32_t j = 0; j < 8u; ++j) qx[j] = q[j].x, qy[j] = q[j].y, qz[j] = q[j].z;
+        } else {
+#pragma unroll
+          for (uint32_t j = 0; j < 8u; ++j) {
+            const float4 q = lights[3u * min(first + j, L - 1u)];
+            qx[j] = q.x, qy[j] = q.y, qz[j] = q.z;
+          }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; ++j) {
+#pragma unroll
+          for (uint32_t i = 0; i < kWalkHome; ++i) raw[i] = push_sign(raw[i], fma_(qz[j], nz[i], fma_(qy[j], ny[i], fma_(qx[j], nx[i], cst[i]))));
+        }
       }
+      const uint32_t valid = valid_bits(w), force = lds.force[w];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) count[i] += __popc(list_word(raw[i] << (32u - n), w, d[i]));
+      for (uint32_t i = 0; i < kWalkHome; ++i) {
+        const uint32_t tested = (~raw[i] | force) & valid;
+        const uint32_t word = kind[i] == 0u ? 0u : (kind[i] == 1u ? tested : valid);
+        lds.mask[w][yl * 32u + xl + i] = word;
+        count[i] += __popc(word);
+      }
     }
-    // counting sort by count / 4 (64 buckets; equal counts stay together, their order among themselves is arbitrary
+    // counting sort by length / 4 (64 buckets; equal lengths stay together, their order among themselves is arbitrary
     // and changes nothing: a pixel's result does not depend on the lane that shades it)
-    uint32_t bucket[4], within[4];
+    uint32_t bucket[kWalkHome], within[kWalkHome];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (uint32_t i = 0; i < kWalkHome; ++i) {
       bucket[i] = min(count[i], 255u) >> 2;
-      within[i] = atomicAdd(&s_hist[bucket[i]], 1u);
+      within[i] = atomicAdd(&lds.hist[bucket[i]], 1u);
     }
     __syncthreads();
     if (wave == 0u) {
-      const uint32_t mine = s_hist[lane];
+      const uint32_t mine = lds.hist[lane];
       uint32_t incl = mine;
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
         const uint32_t up = __shfl_up(incl, off);
         if (lane >= (uint32_t)off) incl += up;
       }
-      s_hist[lane] = incl - mine;
+      lds.hist[lane] = incl - mine;
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) s_order[s_hist[bucket[i]] + within[i]] = (uint16_t)((t >> 3) * 32u + (t & 7u) * 4u + (uint32_t)i);
+    for (uint32_t i = 0; i < kWalkHome; ++i) {
+#ifdef VKR_X_WALK_NOSORT
+      lds.order[t * kWalkHome + i] = (uint16_t)(yl * 32u + xl + i);
+#else
+      lds.order[lds.hist[bucket[i]] + within[i]] = (uint16_t)(yl * 32u + xl + i);
+#endif
+    }
     __syncthreads();
   }
 
@@ -973,43 +1024,33 @@ __global__ __launch_bounds__(256, 4) void deferred_walk_kernel(const DeferredPar
   kc.radius2_scaled = 0.0f;
   Probe probe{0u};
 
-  // ---- four batches of 64 pixels per wave
+  // ---- kWalkHome batches of 64 pixels per wave
 #pragma unroll 1
-  for (uint32_t k = 0; k < 4u; ++k) {
+  for (uint32_t k = 0; k < kWalkHome; ++k) {
     const uint32_t batch = (k & 1u) ? 4u * k + 3u - wave : 4u * k + wave;
-    const uint32_t id = s_order[64u * batch + lane];
-    const uint32_t x = tile_x * 32u + (id & 31u), y = tile_y * 32u + (id >> 5);
+    const uint32_t id = lds.order[64u * batch + lane];
+    const uint32_t x = tile_x * 32u + (id & 31u), y = tile_y * kWalkRows + (id >> 5);
     const bool inside = x < p.width && y < p.height;
-    const uint32_t lx = inside ? x : tile_x * 32u, ly = inside ? y : tile_y * 32u;
+    const uint32_t lx = inside ? x : tile_x * 32u, ly = inside ? y : tile_y * kWalkRows;
     const uint32_t alb = *reinterpret_cast<const uint32_t*>(p.albedo + (size_t)ly * p.pitch_albedo + (size_t)lx * 4u);
     const uint32_t mat = *reinterpret_cast<const uint32_t*>(p.material + (size_t)ly * p.pitch_material + (size_t)lx * 4u);
     const float dep = *reinterpret_cast<const float*>(p.depth + (size_t)ly * p.pitch_depth + (size_t)lx * 4u);
     const uint2 nrm = *reinterpret_cast<const uint2*>(p.normal + (size_t)ly * p.pitch_normal + (size_t)lx * 8u);
     Pixel s;
     setup_pixel(s, p, clip_coord(lx, by_width), clip_coord(ly + p.row_offset, by_height), dep, mat, nrm.x, nrm.y);
-    {
-      const Side d = side_of(s, inside);
-      for (uint32_t w = 0; w < words; ++w) {
-        const uint32_t n = min(32u, L - w * 32u);
-        uint32_t raw = 0u;
-        const float* r = s_rec + w * 32u * kWalkStride;
-        for (uint32_t j = 0; j < n; ++j, r += kWalkStride) raw = push_sign(raw, fma_(r[2], d.nz, fma_(r[1], d.ny, fma_(r[0], d.nx, d.cst))));
-        s_mask[wave][w][lane] = list_word(raw << (32u - n), w, d);
-      }
-    }
-    // one wave: its LDS accesses execute in program order; only the compiler has to be kept from reordering them
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+    const uint32_t* my_words = &lds.mask[0][id];  // word w at my_words[w * kWalkPixels]
     uint32_t cur = 0u, wi = 0u;  // the word being walked (bits of lights not yet taken) and the index of the next one
+#ifdef VKR_X_WALK_NOWALK
+    wi = words;
+#endif
     for (;;) {
       uint32_t at[4];  // dword offsets of this trip's four records
       bool any = false;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         if (cur == 0u && wi < words) {
-          cur = s_mask[wave][wi][lane];
+          cur = my_words[wi * kWalkPixels];
           ++wi;
         }
         const bool has = cur != 0u;
@@ -1023,7 +1064,7 @@ __global__ __launch_bounds__(256, 4) void deferred_walk_kernel(const DeferredPar
       Light four[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float* r = s_rec + at[e];
+        const float* r = lds.rec + at[e];
         four[e] = Light{r[0], r[1], r[2], r[3], r[4], r[5]};
       }
       shade4<false, false>(s, s, four, kc, probe, [] {}, [] {});
@@ -1031,7 +1072,7 @@ __global__ __launch_bounds__(256, 4) void deferred_walk_kernel(const DeferredPar
     float rgb[3];
     finish_pixel(s, alb, mat, true, rgb);
     if (kIs8Bit) {
-      s_out[id] = pack_unorm8<kOutMode>(rgb);
+      lds.out[id] = pack_unorm8<kOutMode>(rgb);
     } else if (inside) {
       uint8_t* orow = p.out + (size_t)y * p.pitch_out;
       if (kOutMode == kOutRgba16f)
@@ -1039,16 +1080,24 @@ __global__ __launch_bounds__(256, 4) void deferred_walk_kernel(const DeferredPar
       else
         reinterpret_cast<float4*>(orow)[x] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
   }
   if (kIs8Bit) {
     __syncthreads();
-    const uint32_t x0 = tile_x * 32u + (t & 7u) * 4u, y = tile_y * 32u + (t >> 3);
+    constexpr uint32_t kLanesPerRow = 32u / kWalkHome;
+    const uint32_t xl = (t % kLanesPerRow) * kWalkHome, yl = t / kLanesPerRow;
+    const uint32_t x0 = tile_x * 32u + xl, y = tile_y * kWalkRows + yl;
     if (y < p.height && x0 < p.width) {
-      const uint32_t at = (t >> 3) * 32u + (t & 7u) * 4u;
-      const uint32_t packed[4] = {s_out[at], s_out[at + 1u], s_out[at + 2u], s_out[at + 3u]};
-      store_rgba8x4(p.out + (size_t)y * p.pitch_out, x0, min(4u, p.width - x0), packed);
+      uint32_t* o = reinterpret_cast<uint32_t*>(p.out + (size_t)y * p.pitch_out) + x0;
+      const uint32_t* r = &lds.out[yl * 32u + xl];
+      if (kWalkHome == 4u && x0 + 3u < p.width) {
+        *reinterpret_cast<uint4*>(o) = make_uint4(r[0], r[1], r[2], r[3]);
+      } else if (kWalkHome == 2u && x0 + 1u < p.width) {
+        *reinterpret_cast<uint2*>(o) = make_uint2(r[0], r[1]);
+      } else {
+#pragma unroll
+        for (uint32_t i = 0; i < kWalkHome; ++i)
+          if (x0 + i < p.width) o[i] = r[i];
+      }
     }
   }
 }
@@ -2121,7 +2170,7 @@ constexpr uint32_t kListMaxLights = 65536;        // list entries are 16-bit lig
 constexpr uint32_t kFineRounds = VKR_X_FINE_ROUNDS;               // whole-table launches of fewer rounds of four-wave workgroups than this shade one pixel per lane
 
 #ifndef VKR_X_WALK_FINE
-#define VKR_X_WALK_FINE 0
+#define VKR_X_WALK_FINE 1
 #endif
 #ifndef VKR_X_WALK_MIN
 #define VKR_X_WALK_MIN 1
@@ -2137,7 +2186,7 @@ hipError_t launch_mode(const DeferredParams& p, const TileListOut* lists, uint32
   const dim3 fine_grid((p.width + 63u) / 64u, p.height, 1u);  // one wave per 64 pixels of a row
   const bool walk = !radius && (p.flags & 4u) == 0u && p.light_count >= kWalkMinLights && p.light_count <= kWalkLights && !(fine && !VKR_X_WALK_FINE);
   if (lists == nullptr && walk) {
-    hipLaunchKernelGGL((deferred_walk_kernel<kOutMode>), grid, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((deferred_walk_kernel<kOutMode>), dim3(grid.x, (p.height + kWalkRows - 1u) / kWalkRows, 1u), dim3(256), 0, stream, p);
   } else if (lists == nullptr) {
     if (!radius && !fine) hipLaunchKernelGGL((deferred_kernel<kOutMode, false, 4>), grid, dim3(256), 0, stream, p);
     if (!radius && fine) hipLaunchKernelGGL((deferred_pixel_kernel<kOutMode, false>), fine_grid, dim3(64), 0, stream, p);
