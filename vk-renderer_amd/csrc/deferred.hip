@@ -833,19 +833,14 @@ __global__ __launch_bounds__(64, 4) void deferred_pixel_kernel(const DeferredPar
 // length (counting sort over 64 buckets in LDS) and dealt out in that order: a wave shades batches of 64 pixels of
 // like lengths, taken so that the four waves of the workgroup end up with like totals (batches w, 7 - w, 8 + w,
 // 15 - w of the order).  Unsorted the kernel is slower than the loops that evaluate everything (2.76 against 2.25 ms).
-// One workgroup per tile of 32 x kWalkRows pixels, at most kWalkLights lights (one LDS chunk; longer tables go to the
-// kernels above).
+// One workgroup per tile of 32 x 16 or 32 x 32 pixels (four or eight waves, every lane prepares two pixels and shades
+// two), at most kWalkLights lights (one LDS chunk; longer tables go to the kernels above).
 constexpr uint32_t kWalkLights = 256;
 constexpr uint32_t kWalkWords = kWalkLights / 32u;
 constexpr uint32_t kWalkStride = 7;   // dwords per staged record (px py pz cx cy cz, one unused): 7 is coprime with the 32 banks
 constexpr float kWalkMargin = 0x1p-20f * kFrameScale;
 constexpr float kWalkFar = 1e15f;
-#ifndef VKR_X_WALK_ROWS
-#define VKR_X_WALK_ROWS 16
-#endif
-constexpr uint32_t kWalkRows = VKR_X_WALK_ROWS;          // 16 or 32
-constexpr uint32_t kWalkPixels = 32u * kWalkRows;        // per tile
-constexpr uint32_t kWalkHome = kWalkPixels / 256u;       // consecutive pixels of a row that a lane prepares
+constexpr uint32_t kWalkHome = 2;  // consecutive pixels of a row that a lane prepares; a wave shades as many batches
 
 // The first 16 bytes of eight consecutive 48-byte light records at a wave-uniform address, through the scalar cache
 // into scalar registers: one address, eight immediate offsets, one wait.  (Written as indexed loads the compiler
@@ -870,6 +865,7 @@ __device__ __forceinline__ void scalar_load_8_records(const float4* base, v4f (&
 // The sign of `v` shifted into `mask` from below: light j of a block of 32 ends up in bit 31 - j.
 __device__ __forceinline__ uint32_t push_sign(uint32_t mask, float v) { return __builtin_amdgcn_alignbit(mask, __float_as_uint(v), 31u); }
 
+template <uint32_t kWalkPixels>
 struct WalkLds {
   float rec[(kWalkLights + 1u) * kWalkStride];  // first, so that a record's dwords are immediate offsets from its address; + the black light, which lanes whose list has ended walk
   uint32_t mask[kWalkWords][kWalkPixels];       // word w of pixel id's list
@@ -878,11 +874,16 @@ struct WalkLds {
   uint32_t lmax;
   uint32_t out[kWalkPixels];                    // 8-bit results by pixel (row << 5 | column within the tile)
   uint16_t order[kWalkPixels];
+  uint16_t length[kWalkPixels];                 // lights on each pixel's list
 };
 
-template <int kOutMode>
-__global__ __launch_bounds__(256, 4) void deferred_walk_kernel(const DeferredParams p) {
-  __shared__ WalkLds lds;
+// kWalkRows = rows of a tile = 16 (four waves) or 32 (eight waves; more pixels to sort, so batches of more even
+// lengths: 24.2 instead of 26.1 trips per batch on the headline frame, where lists of the mean length would take 21.8;
+// as many waves per CU either way)
+template <int kOutMode, uint32_t kWalkRows>
+__global__ __launch_bounds__(16 * kWalkRows, 1024 / (16 * kWalkRows)) void deferred_walk_kernel(const DeferredParams p) {
+  constexpr uint32_t kWalkPixels = 32u * kWalkRows, kThreads = 16u * kWalkRows, kWaves = kThreads / 64u;
+  __shared__ WalkLds<kWalkPixels> lds;
   constexpr bool kIs8Bit = kOutMode == kOutRgba8 || kOutMode == kOutBgra8;
   const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
   const uint32_t L = p.light_count;  // 1 .. kWalkLights
@@ -894,7 +895,7 @@ __global__ __launch_bounds__(256, 4) void deferred_walk_kernel(const DeferredPar
   if (t == 0u) lds.lmax = 0u;
   if (t < 64u) lds.hist[t] = 0u;
   __syncthreads();
-  {
+  if (t < kWalkLights) {  // the first four waves, one light per lane
     float4 lp = make_float4(0.0f, 0.0f, 1e18f, 0.0f), lc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     bool forced = false;
     if (t < L) {
@@ -925,8 +926,7 @@ __global__ __launch_bounds__(256, 4) void deferred_walk_kernel(const DeferredPar
 
   // ---- every pixel's list; lane t prepares the kWalkHome consecutive pixels of its row
   {
-    constexpr uint32_t kLanesPerRow = 32u / kWalkHome;
-    const uint32_t xl = (t % kLanesPerRow) * kWalkHome, yl = t / kLanesPerRow;
+    const uint32_t xl = (t & 15u) * kWalkHome, yl = t >> 4;
     const uint32_t x0 = tile_x * 32u + xl, y = tile_y * kWalkRows + yl;
     const bool row_in = y < p.height && x0 < p.width;
     const uint32_t lx = row_in ? x0 : tile_x * 32u, ly = row_in ? y : tile_y * kWalkRows;  // in bounds by construction
@@ -950,7 +950,13 @@ __global__ __launch_bounds__(256, 4) void deferred_walk_kernel(const DeferredPar
       kind[i] = !(in_image && s.vn > kEarlyOut) ? 0u : (p1 < kWalkFar ? 1u : 2u);
       count[i] = 0u;
     }
+#ifdef VKR_X_WALK_NOMASK
+    for (uint32_t w = 0; w < words; ++w)
+      for (uint32_t i = 0; i < kWalkHome; ++i) lds.mask[w][yl * 32u + xl + i] = 0u;
+    for (uint32_t w = 0; w < 0u; ++w) {
+#else
     for (uint32_t w = 0; w < words; ++w) {
+#endif
       uint32_t raw[kWalkHome];
 #pragma unroll
       for (uint32_t i = 0; i < kWalkHome; ++i) raw[i] = 0u;
@@ -987,6 +993,8 @@ __global__ __launch_bounds__(256, 4) void deferred_walk_kernel(const DeferredPar
         count[i] += __popc(word);
       }
     }
+#pragma unroll
+    for (uint32_t i = 0; i < kWalkHome; ++i) lds.length[yl * 32u + xl + i] = (uint16_t)count[i];
     // counting sort by length / 4 (64 buckets; equal lengths stay together, their order among themselves is arbitrary
     // and changes nothing: a pixel's result does not depend on the lane that shades it)
     uint32_t bucket[kWalkHome], within[kWalkHome];
@@ -1024,10 +1032,10 @@ __global__ __launch_bounds__(256, 4) void deferred_walk_kernel(const DeferredPar
   kc.radius2_scaled = 0.0f;
   Probe probe{0u};
 
-  // ---- kWalkHome batches of 64 pixels per wave
+  // ---- two batches of 64 pixels per wave: one from each end of the order
 #pragma unroll 1
   for (uint32_t k = 0; k < kWalkHome; ++k) {
-    const uint32_t batch = (k & 1u) ? 4u * k + 3u - wave : 4u * k + wave;
+    const uint32_t batch = k == 0u ? wave : 2u * kWaves - 1u - wave;
     const uint32_t id = lds.order[64u * batch + lane];
     const uint32_t x = tile_x * 32u + (id & 31u), y = tile_y * kWalkRows + (id >> 5);
     const bool inside = x < p.width && y < p.height;
@@ -1040,31 +1048,33 @@ __global__ __launch_bounds__(256, 4) void deferred_walk_kernel(const DeferredPar
     setup_pixel(s, p, clip_coord(lx, by_width), clip_coord(ly + p.row_offset, by_height), dep, mat, nrm.x, nrm.y);
 
     const uint32_t* my_words = &lds.mask[0][id];  // word w at my_words[w * kWalkPixels]
-    uint32_t cur = 0u, wi = 0u;  // the word being walked (bits of lights not yet taken) and the index of the next one
+    // `left` = lights of the list not yet taken (may go below zero: the last trip's spare places take the black light);
+    // cur = the word being walked (bits of lights not yet taken), wi = index of the next word
+    int32_t left = (int32_t)lds.length[id];
+    uint32_t cur = 0u, wi = 0u;
 #ifdef VKR_X_WALK_NOWALK
-    wi = words;
+    left = 0;
 #endif
-    for (;;) {
-      uint32_t at[4];  // dword offsets of this trip's four records
-      bool any = false;
+    while (__ballot(left > 0) != 0ull) {
+      uint32_t at[4];  // byte offsets of this trip's four records
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if (cur == 0u && wi < words) {
-          cur = my_words[wi * kWalkPixels];
-          ++wi;
+        const bool has = left > e;
+        if (has && cur == 0u) {
+          do {  // a block of 32 lights none of which is on the list has an empty word
+            cur = my_words[wi * kWalkPixels];
+            ++wi;
+          } while (cur == 0u);
         }
-        const bool has = cur != 0u;
-        const uint32_t pos = (uint32_t)__clz((int)cur);  // 32 for 0
-        at[e] = has ? ((wi - 1u) * 32u + pos) * kWalkStride : kWalkLights * kWalkStride;
-        cur = has ? (cur & ~(0x80000000u >> (pos & 31u))) : 0u;
-        any = any || has;
+        const uint32_t pos = (uint32_t)__clz((int)cur) & 31u;
+        at[e] = has ? ((wi - 1u) * 32u + pos) * (kWalkStride * 4u) : kWalkLights * kWalkStride * 4u;
+        cur = has ? (cur & ~(0x80000000u >> pos)) : cur;
       }
-      const bool more = cur != 0u || wi < words;
-      if (__ballot(any || more) == 0ull) break;
+      left -= 4;
       Light four[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float* r = lds.rec + at[e];
+        const float* r = reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds.rec) + at[e]);
         four[e] = Light{r[0], r[1], r[2], r[3], r[4], r[5]};
       }
       shade4<false, false>(s, s, four, kc, probe, [] {}, [] {});
@@ -1083,21 +1093,15 @@ __global__ __launch_bounds__(256, 4) void deferred_walk_kernel(const DeferredPar
   }
   if (kIs8Bit) {
     __syncthreads();
-    constexpr uint32_t kLanesPerRow = 32u / kWalkHome;
-    const uint32_t xl = (t % kLanesPerRow) * kWalkHome, yl = t / kLanesPerRow;
+    const uint32_t xl = (t & 15u) * kWalkHome, yl = t >> 4;
     const uint32_t x0 = tile_x * 32u + xl, y = tile_y * kWalkRows + yl;
     if (y < p.height && x0 < p.width) {
       uint32_t* o = reinterpret_cast<uint32_t*>(p.out + (size_t)y * p.pitch_out) + x0;
       const uint32_t* r = &lds.out[yl * 32u + xl];
-      if (kWalkHome == 4u && x0 + 3u < p.width) {
-        *reinterpret_cast<uint4*>(o) = make_uint4(r[0], r[1], r[2], r[3]);
-      } else if (kWalkHome == 2u && x0 + 1u < p.width) {
+      if (x0 + 1u < p.width)
         *reinterpret_cast<uint2*>(o) = make_uint2(r[0], r[1]);
-      } else {
-#pragma unroll
-        for (uint32_t i = 0; i < kWalkHome; ++i)
-          if (x0 + i < p.width) o[i] = r[i];
-      }
+      else
+        o[0] = r[0];
     }
   }
 }
@@ -2169,8 +2173,8 @@ constexpr uint32_t kListMaxLights = 65536;        // list entries are 16-bit lig
 #endif
 constexpr uint32_t kFineRounds = VKR_X_FINE_ROUNDS;               // whole-table launches of fewer rounds of four-wave workgroups than this shade one pixel per lane
 
-#ifndef VKR_X_WALK_FINE
-#define VKR_X_WALK_FINE 1
+#ifndef VKR_X_WALK_SMALL_TILES
+#define VKR_X_WALK_SMALL_TILES 0
 #endif
 #ifndef VKR_X_WALK_MIN
 #define VKR_X_WALK_MIN 1
@@ -2184,9 +2188,13 @@ hipError_t launch_mode(const DeferredParams& p, const TileListOut* lists, uint32
   // fewer than kFineRounds rounds of four-wave workgroups (four of them fit a CU): one pixel per lane, single-wave workgroups
   const bool fine = (p.flags & 4u) == 0u && (uint64_t)grid.x * grid.y < (uint64_t)kFineRounds * 4u * cu_count;
   const dim3 fine_grid((p.width + 63u) / 64u, p.height, 1u);  // one wave per 64 pixels of a row
-  const bool walk = !radius && (p.flags & 4u) == 0u && p.light_count >= kWalkMinLights && p.light_count <= kWalkLights && !(fine && !VKR_X_WALK_FINE);
+  const bool walk = !radius && (p.flags & 4u) == 0u && p.light_count >= kWalkMinLights && p.light_count <= kWalkLights;
   if (lists == nullptr && walk) {
-    hipLaunchKernelGGL((deferred_walk_kernel<kOutMode>), dim3(grid.x, (p.height + kWalkRows - 1u) / kWalkRows, 1u), dim3(256), 0, stream, p);
+    // launches of few workgroups (a screen band, a small frame) take the smaller tile: twice as many workgroups to deal out
+    if (fine || VKR_X_WALK_SMALL_TILES)
+      hipLaunchKernelGGL((deferred_walk_kernel<kOutMode, 16>), dim3(grid.x, (p.height + 15u) / 16u, 1u), dim3(256), 0, stream, p);
+    else
+      hipLaunchKernelGGL((deferred_walk_kernel<kOutMode, 32>), grid, dim3(512), 0, stream, p);
   } else if (lists == nullptr) {
     if (!radius && !fine) hipLaunchKernelGGL((deferred_kernel<kOutMode, false, 4>), grid, dim3(256), 0, stream, p);
     if (!radius && fine) hipLaunchKernelGGL((deferred_pixel_kernel<kOutMode, false>), fine_grid, dim3(64), 0, stream, p);
