@@ -501,3 +501,47 @@ def test_non_finite_lights(vkr, synth, oracle, ctx):
         d = np.abs(got8.astype(int) - ref["rgba8"].astype(int))
         d[near] = 0
         assert d.max() <= 1 and (got8[ref_nan & ~near][:, :3] == 0).all()
+
+
+@pytest.mark.parametrize("w,h,lights", [(96, 40, 1), (96, 40, 31), (96, 40, 33), (70, 50, 255), (131, 77, 256), (64, 36, 257)])
+def test_lists_per_pixel_give_the_bytes_of_the_loop_over_every_light(vkr, synth, ctx, w, h, lights):
+    """Up to 256 lights the whole-table resolve gives every pixel a list of the lights that can contribute to it (a
+    one-sided test of l.n against a margin, deferred.comp:43,84) and walks only those; VKR_DEFERRED_WHOLE_TILE_WORKGROUPS
+    selects the loop that evaluates every light on every pixel.  Same bytes, in every format - on lights placed to
+    sit on, just above and just below the tangent planes of pixels of the frame (where the test has to be one-sided),
+    on lights beyond the test's range (1e15 and further), with colours that are not finite, and on a band of a taller
+    frame (row_offset / full_height)."""
+    case = synth.deferred_case(w, h, lights, config_index=9)
+    g, push = case["gbuf"], case["push"]
+    pos = synth.unproject(push[4:20], w, h, g["depth"])  # (h, w, 3), binary64
+    n = g["normal"][..., :3].astype(np.float64)
+    n = -n / np.linalg.norm(n, axis=-1, keepdims=True)
+    rng = np.random.default_rng(lights)
+    rec = np.ascontiguousarray(case["lights"], np.float32).reshape(-1, 12).copy()
+    # every second light onto the tangent plane of a pixel of its own, displaced along the normal by 0, +-1e-7, +-1e-5,
+    # +-1e-3 of the light's distance from the origin (the binary32 rounding of its position does the rest)
+    steps = np.array([0.0, 1e-7, -1e-7, 1e-5, -1e-5, 1e-3, -1e-3])
+    for j in range(0, lights, 2):
+        y, x = int(rng.integers(h)), int(rng.integers(w))
+        t = np.cross(n[y, x], rng.standard_normal(3))
+        t /= np.linalg.norm(t)
+        q = pos[y, x] + t * rng.uniform(0.5, 60.0)
+        q = q + n[y, x] * steps[(j // 2) % len(steps)] * np.abs(q).sum()
+        rec[j, 0:3] = q.astype(np.float32)
+    if lights >= 31:
+        rec[5, 0:3] = (3e15, -1.0, 2.0)      # beyond the range of the test: every pixel walks it
+        rec[7, 0:3] = (1.0, 2e20, -4e22)     # far enough for the squared distance to overflow
+        rec[9, 4:7] = (np.inf, 1.0, 1.0)     # poisons what it reaches, on either path
+        rec[11, 4] = np.nan
+    case = dict(case, lights=rec)
+    for fmt in (vkr.FORMAT_R32G32B32A32_SFLOAT, vkr.FORMAT_R16G16B16A16_SFLOAT, vkr.FORMAT_R8G8B8A8_UNORM, vkr.FORMAT_B8G8R8A8_UNORM):
+        lists, _ = run_deferred_gpu(vkr, ctx, case, fmt)
+        loop, _ = run_deferred_gpu(vkr, ctx, case, fmt, flags=vkr.DEFERRED_WHOLE_TILE_WORKGROUPS)
+        assert np.array_equal(lists.view(np.uint8), loop.view(np.uint8)), fmt
+    rows = (h // 3, h // 3 + 17)
+    lists, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT, rows=rows)
+    loop, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT, flags=vkr.DEFERRED_WHOLE_TILE_WORKGROUPS, rows=rows)
+    assert np.array_equal(lists.view(np.uint8), loop.view(np.uint8))
+    if lights >= 31:
+        full, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT)
+        assert np.isnan(full[..., :3]).any() and np.isfinite(full[..., :3]).any()  # the bad colours reach some pixels, not all
