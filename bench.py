@@ -452,6 +452,25 @@ def main():
     STATE["headline_done"] = True  # every rank is past the headline's last collective: what follows adds to the line
     if cold_ms is not None:
         result["roofline"]["kernel_ms_rotating_4_sets"] = cold_ms
+    # `frac` divides the nominal work - every light on every pixel at the full 117 operations - by the time.  Up to 256
+    # lights the kernel evaluates in full only the pairs whose light is not behind the pixel's surface (the others are
+    # the ones deferred.comp:43,84 returns 0 for; same bytes): the share of such pairs is counted here on a sample of
+    # rows, and `executed_frac` prices what is executed - per pixel 150 + L x 6 (the test) + pairs x 117.
+    if 0 < L <= 256:
+        rows_s = np.arange(0, H, max(H // 24, 1))
+        pos_s = synth.unproject(case["push"][4:20], W, H, case["gbuf"]["depth"])[rows_s]
+        n_s = case["gbuf"]["normal"][rows_s][..., :3].astype(np.float64)
+        n_s = -n_s / np.linalg.norm(n_s, axis=-1, keepdims=True)
+        view_s = case["push"][:3].astype(np.float64) - pos_s
+        front_s = (view_s * n_s).sum(-1) > 0.0
+        lp_s = np.ascontiguousarray(case["lights"], np.float32).reshape(-1, 12)[:, :3].astype(np.float64)
+        ln_s = np.einsum("rwc,lc->rwl", n_s, lp_s) - (pos_s * n_s).sum(-1)[..., None]
+        share = float(((ln_s > 0.0) & front_s[..., None]).mean())
+        executed = float(W) * H * (150.0 + 6.0 * L + 117.0 * L * share)
+        result["roofline"].update({
+            "pairs_evaluated_in_full": share, "executed_flops": executed, "executed_frac": executed / (kern_ms * 1e-3) / VALU_FP32_PEAK,
+            "frac_note": "frac counts every light on every pixel at 117 operations (SURVEY's algorithmic count); the kernel skips, exactly, the pairs "
+                         "whose light lies behind the pixel's surface (deferred.comp:43,84), so frac may exceed 1; executed_frac prices what is executed"})
 
     # ---------------------------------------------------------------- deferred: one frame in bands
     # The pipelines are the package's (vk-renderer_amd/dist.py): double-buffered band / command buffers, the gather

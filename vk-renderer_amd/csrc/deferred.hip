@@ -950,13 +950,18 @@ __global__ __launch_bounds__(16 * kWalkRows, 1024 / (16 * kWalkRows)) void defer
       kind[i] = !(in_image && s.vn > kEarlyOut) ? 0u : (p1 < kWalkFar ? 1u : 2u);
       count[i] = 0u;
     }
+    // a wave none of whose pixels a light can change (sky, back faces) writes its empty lists and skips the tests
+    bool wave_live = false;
+#pragma unroll
+    for (uint32_t i = 0; i < kWalkHome; ++i) wave_live = wave_live || __ballot(kind[i] != 0u) != 0ull;
 #ifdef VKR_X_WALK_NOMASK
-    for (uint32_t w = 0; w < words; ++w)
-      for (uint32_t i = 0; i < kWalkHome; ++i) lds.mask[w][yl * 32u + xl + i] = 0u;
-    for (uint32_t w = 0; w < 0u; ++w) {
-#else
-    for (uint32_t w = 0; w < words; ++w) {
+    wave_live = false;
 #endif
+    if (!wave_live) {
+      for (uint32_t w = 0; w < words; ++w)
+        for (uint32_t i = 0; i < kWalkHome; ++i) lds.mask[w][yl * 32u + xl + i] = 0u;
+    }
+    for (uint32_t w = 0; w < (wave_live ? words : 0u); ++w) {
       uint32_t raw[kWalkHome];
 #pragma unroll
       for (uint32_t i = 0; i < kWalkHome; ++i) raw[i] = 0u;
@@ -1032,18 +1037,36 @@ __global__ __launch_bounds__(16 * kWalkRows, 1024 / (16 * kWalkRows)) void defer
   kc.radius2_scaled = 0.0f;
   Probe probe{0u};
 
-  // ---- two batches of 64 pixels per wave: one from each end of the order
+  // ---- two batches of 64 pixels per wave: one from each end of the order.  Both batches' texels are requested here:
+  // the second batch's arrive while the first is shaded.
+  struct Texels {
+    uint32_t id, alb, mat;
+    float dep;
+    uint2 nrm;
+  };
+  auto fetch = [&](uint32_t k) {
+    Texels q;
+    q.id = lds.order[64u * (k == 0u ? wave : 2u * kWaves - 1u - wave) + lane];
+    const uint32_t x = tile_x * 32u + (q.id & 31u), y = tile_y * kWalkRows + (q.id >> 5);
+    const bool inside = x < p.width && y < p.height;
+    const uint32_t lx = inside ? x : tile_x * 32u, ly = inside ? y : tile_y * kWalkRows;
+    q.alb = *reinterpret_cast<const uint32_t*>(p.albedo + (size_t)ly * p.pitch_albedo + (size_t)lx * 4u);
+    q.mat = *reinterpret_cast<const uint32_t*>(p.material + (size_t)ly * p.pitch_material + (size_t)lx * 4u);
+    q.dep = *reinterpret_cast<const float*>(p.depth + (size_t)ly * p.pitch_depth + (size_t)lx * 4u);
+    q.nrm = *reinterpret_cast<const uint2*>(p.normal + (size_t)ly * p.pitch_normal + (size_t)lx * 8u);
+    return q;
+  };
+  Texels ahead = fetch(0u);
 #pragma unroll 1
   for (uint32_t k = 0; k < kWalkHome; ++k) {
-    const uint32_t batch = k == 0u ? wave : 2u * kWaves - 1u - wave;
-    const uint32_t id = lds.order[64u * batch + lane];
+    const Texels q = ahead;
+    if (k + 1u < kWalkHome) ahead = fetch(k + 1u);
+    const uint32_t id = q.id, alb = q.alb, mat = q.mat;
+    const float dep = q.dep;
+    const uint2 nrm = q.nrm;
     const uint32_t x = tile_x * 32u + (id & 31u), y = tile_y * kWalkRows + (id >> 5);
     const bool inside = x < p.width && y < p.height;
     const uint32_t lx = inside ? x : tile_x * 32u, ly = inside ? y : tile_y * kWalkRows;
-    const uint32_t alb = *reinterpret_cast<const uint32_t*>(p.albedo + (size_t)ly * p.pitch_albedo + (size_t)lx * 4u);
-    const uint32_t mat = *reinterpret_cast<const uint32_t*>(p.material + (size_t)ly * p.pitch_material + (size_t)lx * 4u);
-    const float dep = *reinterpret_cast<const float*>(p.depth + (size_t)ly * p.pitch_depth + (size_t)lx * 4u);
-    const uint2 nrm = *reinterpret_cast<const uint2*>(p.normal + (size_t)ly * p.pitch_normal + (size_t)lx * 8u);
     Pixel s;
     setup_pixel(s, p, clip_coord(lx, by_width), clip_coord(ly + p.row_offset, by_height), dep, mat, nrm.x, nrm.y);
 
