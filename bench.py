@@ -34,7 +34,7 @@ VALU_FP32_PEAK = 157.3e12  # FLOP/s, vector FP32 (spec)
 
 
 # Kernel names under which the committed PMC passes (profiles/rNN_pmc.json) list the HBM traffic per launch.
-PMC_DEFERRED = "deferred_kernel<0, false, 4>"
+PMC_DEFERRED = "deferred_walk_kernel<0, 32u>"  # the headline launch: per-pixel lists, 32 x 32 tiles, rgba8
 PMC_TILED = ("light_bins_kernel", "tile_lists_kernel<0>", "deferred_lists_kernel<0>")
 PMC_CULL = {"atomic": ("cull_init_cmds", "cull_atomic_kernel"), "deterministic": ("cull_onepass_kernel",)}
 
@@ -442,7 +442,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"deferred resolve {W}x{H}, {L} point lights, rgba8 output, one frame per GPU per step",
                    "width": W, "height": H, "lights": L, "parallelism": f"frame-batch x{world}", "device": info["name"]},
-        "roofline": {"bound": "valu_fp32", "kernel": "deferred_kernel", "achieved": ach_flops / 1e12, "peak": VALU_FP32_PEAK / 1e12,
+        "roofline": {"bound": "valu_fp32", "kernel": "deferred_walk_kernel", "achieved": ach_flops / 1e12, "peak": VALU_FP32_PEAK / 1e12,
                      "unit": "TFLOP/s", "frac": ach_flops / VALU_FP32_PEAK, "traffic": d_traffic,
                      "traffic_source": pmc_file if d_traffic is not None else None,
                      "kernel_ms": kern_ms, "kernel_ms_median": float(np.median(step_ms)), "kernel_ms_min": float(min(step_ms)),

@@ -125,11 +125,13 @@ typedef struct vkr_image2d {
                                          graph: the launches take a value the host advances per call. */
 #define VKR_DEFERRED_NO_TILE_LISTS 2u /* with RADIUS_CUTOFF: apply the cutoff per pixel only and loop over the whole
                                          light table (diagnostic; results are bit-identical to the tiled path) */
-#define VKR_DEFERRED_WHOLE_TILE_WORKGROUPS 4u /* whole-table loop: always one 256-thread workgroup per 32 x 32 pixel
-                                         tile.  Without it a launch of fewer than four rounds of such workgroups (a
-                                         small frame, a screen band) runs as single-wave workgroups of 64 pixels of a
-                                         row, one per lane, which shortens the end of the launch (diagnostic;
-                                         bit-identical results) */
+#define VKR_DEFERRED_WHOLE_TILE_WORKGROUPS 4u /* whole-table resolve: always the loop that evaluates every light on
+                                         every pixel, one 256-thread workgroup per 32 x 32 pixel tile.  Without it a
+                                         table of up to 256 lights is resolved from per-pixel lists (every pixel walks only
+                                         the lights that are not behind its surface: the ones deferred.comp:43,84 does
+                                         not return 0 for), and a longer table in a launch of fewer than four rounds of
+                                         such workgroups (a small frame, a screen band) by single-wave workgroups of 64
+                                         pixels of a row (diagnostic; bit-identical results either way) */
 
 /* One dispatch of /root/reference/shaders/deferred.comp (main, :98-131) as recorded at
  * /root/reference/src/main.cpp:222-226.  Bindings follow main.cpp:163-167,190-196:
