@@ -503,9 +503,9 @@ def test_non_finite_lights(vkr, synth, oracle, ctx):
         assert d.max() <= 1 and (got8[ref_nan & ~near][:, :3] == 0).all()
 
 
-@pytest.mark.parametrize("w,h,lights", [(96, 40, 1), (96, 40, 31), (96, 40, 33), (70, 50, 255), (131, 77, 256), (64, 36, 257)])
+@pytest.mark.parametrize("w,h,lights", [(96, 40, 24), (96, 40, 31), (96, 40, 33), (70, 50, 255), (131, 77, 256), (64, 36, 257)])
 def test_lists_per_pixel_give_the_bytes_of_the_loop_over_every_light(vkr, synth, ctx, w, h, lights):
-    """Up to 256 lights the whole-table resolve gives every pixel a list of the lights that can contribute to it (a
+    """From 24 to 256 lights the whole-table resolve gives every pixel a list of the lights that can contribute to it (a
     one-sided test of l.n against a margin, deferred.comp:43,84) and walks only those; VKR_DEFERRED_WHOLE_TILE_WORKGROUPS
     selects the loop that evaluates every light on every pixel.  Same bytes, in every format - on lights placed to
     sit on, just above and just below the tangent planes of pixels of the frame (where the test has to be one-sided),
@@ -528,7 +528,7 @@ def test_lists_per_pixel_give_the_bytes_of_the_loop_over_every_light(vkr, synth,
         q = pos[y, x] + t * rng.uniform(0.5, 60.0)
         q = q + n[y, x] * steps[(j // 2) % len(steps)] * np.abs(q).sum()
         rec[j, 0:3] = q.astype(np.float32)
-    if lights >= 31:
+    if lights >= 24:
         rec[5, 0:3] = (3e15, -1.0, 2.0)      # beyond the range of the test: every pixel walks it
         rec[7, 0:3] = (1.0, 2e20, -4e22)     # far enough for the squared distance to overflow
         rec[9, 4:7] = (np.inf, 1.0, 1.0)     # poisons what it reaches, on either path
@@ -542,6 +542,6 @@ def test_lists_per_pixel_give_the_bytes_of_the_loop_over_every_light(vkr, synth,
     lists, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT, rows=rows)
     loop, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT, flags=vkr.DEFERRED_WHOLE_TILE_WORKGROUPS, rows=rows)
     assert np.array_equal(lists.view(np.uint8), loop.view(np.uint8))
-    if lights >= 31:
+    if lights >= 24:
         full, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT)
         assert np.isnan(full[..., :3]).any() and np.isfinite(full[..., :3]).any()  # the bad colours reach some pixels, not all
