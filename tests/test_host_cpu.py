@@ -367,3 +367,56 @@ def test_other_kernels_use_no_scratch_memory(unit):
         name = re.search(r"\.name:\s+(\S+)", block).group(1)
         assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", block).group(1)) == 0, name
         assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", block).group(1)) == 0, name
+
+
+def _fma32(a, b, c):
+    """float(a * b + c) for binary32 operands: the product of two binary32 numbers is exact in binary64, the sum is
+    rounded to binary64 and then to binary32 (a double rounding that can differ from a fused multiply-add by half a
+    binary32 ulp in one case in ~2^29: far inside the margin under test)."""
+    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+
+
+def test_the_per_pixel_list_test_is_one_sided(synth):
+    """The resolve's per-pixel light lists (deferred_walk_kernel) leave a light off a pixel's list when
+    l.n' - p.n' + margin < 0, with n' the shading normal times sqrt(1e7) and margin = 2^-20 * sqrt(1e7) * (|p|_1 + max |l|_1)
+    + 1e-15 - three multiply-adds on the light's position.  A light may only be left off if the loop that evaluates every
+    light would give it weights of exactly zero, i.e. if that loop's own l.n' - the multiply-add chain over the rounded
+    light vector l - p - is negative.  Restated here in binary32 and checked on random pairs, on lights within a few ulps
+    of tangent planes, and on positions of very different magnitudes: never a light dropped that the loop would keep."""
+    rng = np.random.default_rng(7)
+    S = np.float32(3162.27766)
+    n_pairs = 2_000_000
+    scale = np.float32(10.0) ** rng.integers(-3, 6, n_pairs).astype(np.float32)
+    p = (rng.standard_normal((n_pairs, 3)).astype(np.float32) * scale[:, None]).astype(np.float32)
+    n = rng.standard_normal((n_pairs, 3)).astype(np.float32)
+    n = (n / np.linalg.norm(n, axis=1, keepdims=True)).astype(np.float32)
+    ns = (n * S).astype(np.float32)
+    # lights: a third anywhere, two thirds on the pixel's tangent plane, displaced along the normal by 0 .. a few 1e-7 of
+    # the magnitudes involved, in both directions
+    t = np.cross(n, rng.standard_normal((n_pairs, 3))).astype(np.float64)
+    t /= np.linalg.norm(t, axis=1, keepdims=True)
+    lscale = np.float32(10.0) ** rng.integers(-3, 6, n_pairs).astype(np.float32)
+    on_plane = p.astype(np.float64) + t * (rng.uniform(0.01, 100.0, n_pairs) * lscale)[:, None]
+    mag = np.abs(on_plane).sum(1) + np.abs(p.astype(np.float64)).sum(1)
+    nudge = rng.choice([0.0, 1e-8, -1e-8, 1e-7, -1e-7, 3e-7, -3e-7, 1e-6, -1e-6, 3e-6, -3e-6], n_pairs)
+    on_plane = on_plane + n.astype(np.float64) * (nudge * mag)[:, None]
+    anywhere = rng.standard_normal((n_pairs, 3)) * lscale[:, None]
+    l = np.where((np.arange(n_pairs) % 3 == 0)[:, None], anywhere, on_plane).astype(np.float32)
+    lmax = np.float32(np.abs(l).sum(1).max())  # the kernel uses the table's largest |l|_1; here every pair also gets its own
+    for lm in (lmax, None):
+        l1 = np.abs(l).sum(1).astype(np.float32) if lm is None else np.full(n_pairs, lm, np.float32)
+        p1 = ((np.abs(p[:, 0]) + np.abs(p[:, 1])) + np.abs(p[:, 2])).astype(np.float32)
+        pn = _fma32(p[:, 2], ns[:, 2], _fma32(p[:, 1], ns[:, 1], (p[:, 0] * ns[:, 0]).astype(np.float32)))
+        margin = _fma32(np.full(n_pairs, np.float32(2.0 ** -20) * S, np.float32), (p1 + l1).astype(np.float32), np.full(n_pairs, 1e-15, np.float32))
+        cst = (margin - pn).astype(np.float32)
+        fast = _fma32(l[:, 2], ns[:, 2], _fma32(l[:, 1], ns[:, 1], _fma32(l[:, 0], ns[:, 0], cst)))
+        w = (l - p).astype(np.float32)
+        loop = _fma32(w[:, 2], ns[:, 2], _fma32(w[:, 1], ns[:, 1], (w[:, 0] * ns[:, 0]).astype(np.float32)))
+        dropped = np.signbit(fast)
+        assert dropped.any() and (~dropped).any()
+        assert (loop[dropped] < 0).all(), "a light left off a list whose cosine the loop would not find negative"
+        # and not by a hair: the loop's value is at least a third of the margin below zero
+        assert (loop[dropped] <= -0.3 * margin[dropped]).all()
+    # the test is not vacuous near the plane: with each pair's own |l|_1 most lights a clear distance behind are dropped
+    behind = loop < -4.0 * margin
+    assert dropped[behind].mean() > 0.99
