@@ -835,6 +835,10 @@ __global__ __launch_bounds__(64, 4) void deferred_pixel_kernel(const DeferredPar
 // 15 - w of the order).  Unsorted the kernel is slower than the loops that evaluate everything (2.76 against 2.25 ms).
 // One workgroup per tile of 32 x 16 or 32 x 32 pixels (four or eight waves, every lane prepares two pixels and shades
 // two), at most kWalkLights lights (one LDS chunk; longer tables go to the kernels above).
+// Measurement builds (tools/build_variants.sh, tools/ab_deferred.py): -DVKR_X_WALK_NOMASK builds empty lists,
+// -DVKR_X_WALK_NOWALK builds the lists and walks none, -DVKR_X_WALK_NOSORT deals the pixels out unsorted,
+// -DVKR_X_WALK_SMALL_TILES=1 uses the small tile for every launch, -DVKR_X_WALK_MIN=n moves the light count from which
+// the kernel is used.
 constexpr uint32_t kWalkLights = 256;
 constexpr uint32_t kWalkWords = kWalkLights / 32u;
 constexpr uint32_t kWalkStride = 7;   // dwords per staged record (px py pz cx cy cz, one unused): 7 is coprime with the 32 banks
