@@ -127,9 +127,9 @@ typedef struct vkr_image2d {
                                          light table (diagnostic; results are bit-identical to the tiled path) */
 #define VKR_DEFERRED_WHOLE_TILE_WORKGROUPS 4u /* whole-table resolve: always the loop that evaluates every light on
                                          every pixel, one 256-thread workgroup per 32 x 32 pixel tile.  Without it a
-                                         table of 24 to 256 lights is resolved from per-pixel lists (every pixel walks only
+                                         table of 24 lights or more is resolved from per-pixel lists (every pixel walks only
                                          the lights that are not behind its surface: the ones deferred.comp:43,84 does
-                                         not return 0 for), and a shorter or longer table in a launch of fewer than four rounds of
+                                         not return 0 for), and a shorter table in a launch of fewer than four rounds of
                                          such workgroups (a small frame, a screen band) by single-wave workgroups of 64
                                          pixels of a row (diagnostic; bit-identical results either way) */
 

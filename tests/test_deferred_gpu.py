@@ -503,9 +503,9 @@ def test_non_finite_lights(vkr, synth, oracle, ctx):
         assert d.max() <= 1 and (got8[ref_nan & ~near][:, :3] == 0).all()
 
 
-@pytest.mark.parametrize("w,h,lights", [(96, 40, 24), (96, 40, 31), (96, 40, 33), (70, 50, 255), (131, 77, 256), (64, 36, 257)])
+@pytest.mark.parametrize("w,h,lights", [(96, 40, 24), (96, 40, 31), (96, 40, 33), (70, 50, 255), (131, 77, 256), (64, 36, 257), (50, 40, 600)])
 def test_lists_per_pixel_give_the_bytes_of_the_loop_over_every_light(vkr, synth, ctx, w, h, lights):
-    """From 24 to 256 lights the whole-table resolve gives every pixel a list of the lights that can contribute to it (a
+    """From 24 lights up the whole-table resolve gives every pixel a list of the lights that can contribute to it (a
     one-sided test of l.n against a margin, deferred.comp:43,84) and walks only those; VKR_DEFERRED_WHOLE_TILE_WORKGROUPS
     selects the loop that evaluates every light on every pixel.  Same bytes, in every format - on lights placed to
     sit on, just above and just below the tangent planes of pixels of the frame (where the test has to be one-sided),

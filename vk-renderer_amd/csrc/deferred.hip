@@ -834,7 +834,7 @@ __global__ __launch_bounds__(64, 4) void deferred_pixel_kernel(const DeferredPar
 // like lengths, taken so that the four waves of the workgroup end up with like totals (batches w, 7 - w, 8 + w,
 // 15 - w of the order).  Unsorted the kernel is slower than the loops that evaluate everything (2.76 against 2.25 ms).
 // One workgroup per tile of 32 x 16 or 32 x 32 pixels (four or eight waves, every lane prepares two pixels and shades
-// two), at most kWalkLights lights (one LDS chunk; longer tables go to the kernels above).
+// two); a table of more than kWalkLights lights is taken that many at a time (kChunked).
 // Measurement builds (tools/build_variants.sh, tools/ab_deferred.py): -DVKR_X_WALK_NOMASK builds empty lists,
 // -DVKR_X_WALK_NOWALK builds the lists and walks none, -DVKR_X_WALK_NOSORT deals the pixels out unsorted,
 // -DVKR_X_WALK_SMALL_TILES=1 uses the small tile for every launch, -DVKR_X_WALK_MIN=n moves the light count from which
@@ -869,7 +869,7 @@ __device__ __forceinline__ void scalar_load_8_records(const float4* base, v4f (&
 // The sign of `v` shifted into `mask` from below: light j of a block of 32 ends up in bit 31 - j.
 __device__ __forceinline__ uint32_t push_sign(uint32_t mask, float v) { return __builtin_amdgcn_alignbit(mask, __float_as_uint(v), 31u); }
 
-template <uint32_t kWalkPixels>
+template <uint32_t kWalkPixels, bool kChunked>
 struct WalkLds {
   float rec[(kWalkLights + 1u) * kWalkStride];  // first, so that a record's dwords are immediate offsets from its address; + the black light, which lanes whose list has ended walk
   uint32_t mask[kWalkWords][kWalkPixels];       // word w of pixel id's list
@@ -879,25 +879,40 @@ struct WalkLds {
   uint32_t out[kWalkPixels];                    // 8-bit results by pixel (row << 5 | column within the tile)
   uint16_t order[kWalkPixels];
   uint16_t length[kWalkPixels];                 // lights on each pixel's list
+  float sums[kChunked ? 6 : 1][kChunked ? kWalkPixels : 1];  // tables of several chunks: every pixel's two sums between chunks
 };
 
 // kWalkRows = rows of a tile = 16 (four waves) or 32 (eight waves; more pixels to sort, so batches of more even
 // lengths: 24.2 instead of 26.1 trips per batch on the headline frame, where lists of the mean length would take 21.8;
 // as many waves per CU either way)
-template <int kOutMode, uint32_t kWalkRows>
-__global__ __launch_bounds__(16 * kWalkRows, 1024 / (16 * kWalkRows)) void deferred_walk_kernel(const DeferredParams p) {
+// kChunked: the table is longer than kWalkLights and is taken in chunks (below).
+template <int kOutMode, uint32_t kWalkRows, bool kChunked>
+__global__ __launch_bounds__(16 * kWalkRows, kChunked ? 4 : 1024 / (16 * kWalkRows)) void deferred_walk_kernel(const DeferredParams p) {
   constexpr uint32_t kWalkPixels = 32u * kWalkRows, kThreads = 16u * kWalkRows, kWaves = kThreads / 64u;
-  __shared__ WalkLds<kWalkPixels> lds;
+  __shared__ WalkLds<kWalkPixels, kChunked> lds;
   constexpr bool kIs8Bit = kOutMode == kOutRgba8 || kOutMode == kOutBgra8;
   const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-  const uint32_t L = p.light_count;  // 1 .. kWalkLights
-  const uint32_t words = (L + 31u) / 32u;
   const uint32_t tile_x = blockIdx.x, tile_y = blockIdx.y;
-  const float4* __restrict__ lights = reinterpret_cast<const float4*>(p.lights);
+  // A table of more than kWalkLights lights is taken that many at a time (kChunked).  The order in which the pixels
+  // are dealt out is that of the first chunk's lists (a pixel that faces the bulk of one chunk's lights faces the bulk
+  // of the next one's), so a pixel stays with its lane, and its two sums wait in LDS from one chunk to the next.
+#pragma unroll 1
+  for (uint32_t chunk0 = 0; chunk0 < (kChunked ? p.light_count : 1u); chunk0 += kWalkLights) {
+  const uint32_t L = min(kWalkLights, p.light_count - chunk0);  // 1 .. kWalkLights
+  const bool first_chunk = !kChunked || chunk0 == 0u, last_chunk = !kChunked || chunk0 + kWalkLights >= p.light_count;
+  const uint32_t words = (L + 31u) / 32u;
+  const float4* __restrict__ lights = reinterpret_cast<const float4*>(p.lights) + 3u * chunk0;
 
-  // ---- the table into LDS; which lights every pixel must walk; the largest |l|_1 of the others
+  // (several chunks: derived per chunk, through copies the compiler cannot see through, rather than kept in registers
+  // across the chunks)
+  uint32_t width = p.width, full_height = p.full_height;
+  if (kChunked) asm volatile("" : "+s"(width), "+s"(full_height));
+  const ExactRcp by_width = exact_rcp((float)width), by_height = exact_rcp((float)full_height);
+
+  // ---- the chunk into LDS; which lights every pixel must walk; the largest |l|_1 of the others
+  if (!first_chunk) __syncthreads();  // the walks over the previous chunk's records and lists have ended
   if (t == 0u) lds.lmax = 0u;
-  if (t < 64u) lds.hist[t] = 0u;
+  if (first_chunk && t < 64u) lds.hist[t] = 0u;
   __syncthreads();
   if (t < kWalkLights) {  // the first four waves, one light per lane
     float4 lp = make_float4(0.0f, 0.0f, 1e18f, 0.0f), lc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -926,11 +941,11 @@ __global__ __launch_bounds__(16 * kWalkRows, 1024 / (16 * kWalkRows)) void defer
   // bits of word w that stand for lights of the table
   auto valid_bits = [&](uint32_t w) -> uint32_t { return (w + 1u) * 32u <= L ? 0xFFFFFFFFu : (w * 32u < L ? 0xFFFFFFFFu << (32u - (L & 31u)) : 0u); };
 
-  const ExactRcp by_width = exact_rcp((float)p.width), by_height = exact_rcp((float)p.full_height);
-
   // ---- every pixel's list; lane t prepares the kWalkHome consecutive pixels of its row
   {
-    const uint32_t xl = (t & 15u) * kWalkHome, yl = t >> 4;
+    uint32_t tq = t;
+    if (kChunked) asm volatile("" : "+v"(tq));  // what follows is the same for every chunk: derived again, not kept across the walks
+    const uint32_t xl = (tq & 15u) * kWalkHome, yl = tq >> 4;
     const uint32_t x0 = tile_x * 32u + xl, y = tile_y * kWalkRows + yl;
     const bool row_in = y < p.height && x0 < p.width;
     const uint32_t lx = row_in ? x0 : tile_x * 32u, ly = row_in ? y : tile_y * kWalkRows;  // in bounds by construction
@@ -1006,6 +1021,7 @@ __global__ __launch_bounds__(16 * kWalkRows, 1024 / (16 * kWalkRows)) void defer
     for (uint32_t i = 0; i < kWalkHome; ++i) lds.length[yl * 32u + xl + i] = (uint16_t)count[i];
     // counting sort by length / 4 (64 buckets; equal lengths stay together, their order among themselves is arbitrary
     // and changes nothing: a pixel's result does not depend on the lane that shades it)
+    if (first_chunk) {
     uint32_t bucket[kWalkHome], within[kWalkHome];
 #pragma unroll
     for (uint32_t i = 0; i < kWalkHome; ++i) {
@@ -1031,6 +1047,7 @@ __global__ __launch_bounds__(16 * kWalkRows, 1024 / (16 * kWalkRows)) void defer
 #else
       lds.order[lds.hist[bucket[i]] + within[i]] = (uint16_t)(yl * 32u + xl + i);
 #endif
+    }
     }
     __syncthreads();
   }
@@ -1073,6 +1090,10 @@ __global__ __launch_bounds__(16 * kWalkRows, 1024 / (16 * kWalkRows)) void defer
     const uint32_t lx = inside ? x : tile_x * 32u, ly = inside ? y : tile_y * kWalkRows;
     Pixel s;
     setup_pixel(s, p, clip_coord(lx, by_width), clip_coord(ly + p.row_offset, by_height), dep, mat, nrm.x, nrm.y);
+    if (kChunked && !first_chunk) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) s.s1[i] = lds.sums[i][id], s.s2[i] = lds.sums[3 + i][id];
+    }
 
     const uint32_t* my_words = &lds.mask[0][id];  // word w at my_words[w * kWalkPixels]
     // `left` = lights of the list not yet taken (may go below zero: the last trip's spare places take the black light);
@@ -1106,18 +1127,25 @@ __global__ __launch_bounds__(16 * kWalkRows, 1024 / (16 * kWalkRows)) void defer
       }
       shade4<false, false>(s, s, four, kc, probe, [] {}, [] {});
     }
-    float rgb[3];
-    finish_pixel(s, alb, mat, true, rgb);
-    if (kIs8Bit) {
-      lds.out[id] = pack_unorm8<kOutMode>(rgb);
-    } else if (inside) {
-      uint8_t* orow = p.out + (size_t)y * p.pitch_out;
-      if (kOutMode == kOutRgba16f)
-        reinterpret_cast<uint2*>(orow)[x] = half_texel(rgb[0], rgb[1], rgb[2]);
-      else
-        reinterpret_cast<float4*>(orow)[x] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
+    if (kChunked && !last_chunk) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) lds.sums[i][id] = s.s1[i], lds.sums[3 + i][id] = s.s2[i];
+    }
+    if (last_chunk) {
+      float rgb[3];
+      finish_pixel(s, alb, mat, true, rgb);
+      if (kIs8Bit) {
+        lds.out[id] = pack_unorm8<kOutMode>(rgb);
+      } else if (inside) {
+        uint8_t* orow = p.out + (size_t)y * p.pitch_out;
+        if (kOutMode == kOutRgba16f)
+          reinterpret_cast<uint2*>(orow)[x] = half_texel(rgb[0], rgb[1], rgb[2]);
+        else
+          reinterpret_cast<float4*>(orow)[x] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
+      }
     }
   }
+  }  // chunks
   if (kIs8Bit) {
     __syncthreads();
     const uint32_t xl = (t & 15u) * kWalkHome, yl = t >> 4;
@@ -2218,13 +2246,22 @@ hipError_t launch_mode(const DeferredParams& p, const TileListOut* lists, uint32
   // fewer than kFineRounds rounds of four-wave workgroups (four of them fit a CU): one pixel per lane, single-wave workgroups
   const bool fine = (p.flags & 4u) == 0u && (uint64_t)grid.x * grid.y < (uint64_t)kFineRounds * 4u * cu_count;
   const dim3 fine_grid((p.width + 63u) / 64u, p.height, 1u);  // one wave per 64 pixels of a row
-  const bool walk = !radius && (p.flags & 4u) == 0u && p.light_count >= kWalkMinLights && p.light_count <= kWalkLights;
+  const bool walk = !radius && (p.flags & 4u) == 0u && p.light_count >= kWalkMinLights;
   if (lists == nullptr && walk) {
     // launches of few workgroups (a screen band, a small frame) take the smaller tile: twice as many workgroups to deal out
-    if (fine || VKR_X_WALK_SMALL_TILES)
-      hipLaunchKernelGGL((deferred_walk_kernel<kOutMode, 16>), dim3(grid.x, (p.height + 15u) / 16u, 1u), dim3(256), 0, stream, p);
-    else
-      hipLaunchKernelGGL((deferred_walk_kernel<kOutMode, 32>), grid, dim3(512), 0, stream, p);
+    const bool chunked = p.light_count > kWalkLights;
+    const dim3 small_grid(grid.x, (p.height + 15u) / 16u, 1u);
+    if (fine || VKR_X_WALK_SMALL_TILES) {
+      if (chunked)
+        hipLaunchKernelGGL((deferred_walk_kernel<kOutMode, 16, true>), small_grid, dim3(256), 0, stream, p);
+      else
+        hipLaunchKernelGGL((deferred_walk_kernel<kOutMode, 16, false>), small_grid, dim3(256), 0, stream, p);
+    } else {
+      if (chunked)
+        hipLaunchKernelGGL((deferred_walk_kernel<kOutMode, 32, true>), grid, dim3(512), 0, stream, p);
+      else
+        hipLaunchKernelGGL((deferred_walk_kernel<kOutMode, 32, false>), grid, dim3(512), 0, stream, p);
+    }
   } else if (lists == nullptr) {
     if (!radius && !fine) hipLaunchKernelGGL((deferred_kernel<kOutMode, false, 4>), grid, dim3(256), 0, stream, p);
     if (!radius && fine) hipLaunchKernelGGL((deferred_pixel_kernel<kOutMode, false>), fine_grid, dim3(64), 0, stream, p);
