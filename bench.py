@@ -34,7 +34,7 @@ VALU_FP32_PEAK = 157.3e12  # FLOP/s, vector FP32 (spec)
 
 
 # Kernel names under which the committed PMC passes (profiles/rNN_pmc.json) list the HBM traffic per launch.
-PMC_DEFERRED = "deferred_walk_kernel<0, 32u>"  # the headline launch: per-pixel lists, 32 x 32 tiles, rgba8
+PMC_DEFERRED = "deferred_walk_kernel<0, 32u, false>"  # the headline launch: per-pixel lists, 32 x 32 tiles, rgba8
 PMC_TILED = ("light_bins_kernel", "tile_lists_kernel<0>", "deferred_lists_kernel<0>")
 PMC_CULL = {"atomic": ("cull_init_cmds", "cull_atomic_kernel"), "deterministic": ("cull_onepass_kernel",)}
 

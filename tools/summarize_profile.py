@@ -48,13 +48,13 @@ def headline_launches():
     if not trace or not os.path.exists(line_path):
         return
     line = json.load(open(line_path))
-    rows = [r for r in csv.DictReader(open(max(trace, key=os.path.getmtime))) if "deferred_walk_kernel<0, 32" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(max(trace, key=os.path.getmtime))) if "deferred_walk_kernel<0, 32u, false>" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
     w, k = line["warmup"], line["steps"]
     first = (max(w, 4) + k) if "kernel_ms_rotating_4_sets" in line["roofline"] else 0  # the rotating-sets run comes first
     timed = dur[first + w:first + w + k]
-    res = {"kernel": "deferred_walk_kernel<0, 32u>", "launches_in_trace": len(dur), "mean_all_launches_ms": sum(dur) / len(dur) / 1e6,
+    res = {"kernel": "deferred_walk_kernel<0, 32u, false>", "launches_in_trace": len(dur), "mean_all_launches_ms": sum(dur) / len(dur) / 1e6,
            "timed_steps": {"launches": len(timed), "mean_ms": sum(timed) / len(timed) / 1e6, "median_ms": sorted(timed)[len(timed) // 2] / 1e6, "min_ms": min(timed) / 1e6},
            "first_launches_ms": [d / 1e6 for d in dur[:max(w, 4)]],
            "bench_line_kernel_ms": line["roofline"]["kernel_ms"], "bench_line_kernel_ms_median": line["roofline"]["kernel_ms_median"]}
