@@ -533,7 +533,15 @@ def test_lists_per_pixel_give_the_bytes_of_the_loop_over_every_light(vkr, synth,
         rec[7, 0:3] = (1.0, 2e20, -4e22)     # far enough for the squared distance to overflow
         rec[9, 4:7] = (np.inf, 1.0, 1.0)     # poisons what it reaches, on either path
         rec[11, 4] = np.nan
-    case = dict(case, lights=rec)
+        rec[13, 1] = np.nan                  # positions that are not numbers
+        rec[15, 0:3] = (np.inf, 0.0, -np.inf)
+    g = {k: v.copy() for k, v in g.items()}
+    g["normal"][3, 10:14, :3] = 0.0          # cleared texels (normalize(0)), a NaN normal, depths that are not numbers
+    g["normal"][4, 20, 1] = np.float16(np.nan)
+    g["depth"][5, 30] = np.nan
+    g["depth"][6, 31] = np.inf
+    g["depth"][7, 32:40] = 1.0               # the far plane: positions 10 000 units out
+    case = dict(case, gbuf=g, lights=rec)
     for fmt in (vkr.FORMAT_R32G32B32A32_SFLOAT, vkr.FORMAT_R16G16B16A16_SFLOAT, vkr.FORMAT_R8G8B8A8_UNORM, vkr.FORMAT_B8G8R8A8_UNORM):
         lists, _ = run_deferred_gpu(vkr, ctx, case, fmt)
         loop, _ = run_deferred_gpu(vkr, ctx, case, fmt, flags=vkr.DEFERRED_WHOLE_TILE_WORKGROUPS)
@@ -545,3 +553,4 @@ def test_lists_per_pixel_give_the_bytes_of_the_loop_over_every_light(vkr, synth,
     if lights >= 24:
         full, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT)
         assert np.isnan(full[..., :3]).any() and np.isfinite(full[..., :3]).any()  # the bad colours reach some pixels, not all
+        assert np.isnan(full[3, 10:14, :3]).all()  # cleared texels: normalize(0)
