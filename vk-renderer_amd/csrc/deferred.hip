@@ -182,7 +182,7 @@ __device__ __forceinline__ uint32_t probe_budget_for(uint32_t trips, uint32_t le
 // The four (pixel, light) pairs of a trip are two lights on two pixels (kLights = 2: pairs k = 0..3 are (a,L0) (b,L0)
 // (a,L1) (b,L1)) or four lights on one pixel (kLights = 4: (a,L0) .. (a,L3); b is a).  Either way a pixel's sums take
 // its lights in table order.
-template <bool kRadius, bool kProbe, int kLights, class FetchPos, class FetchCol>
+template <bool kRadius, bool kProbe, int kLights, class FetchPos, class FetchCol, bool kAhead = false>
 __device__ __forceinline__ void shade4(Pixel& a, Pixel& b, const Light (&L)[kLights], const LoopConsts& kc, Probe& probe, FetchPos&& fetch_next_pos,
                                        FetchCol&& fetch_next_col) {
   static_assert(kLights == 2 || kLights == 4, "two lights on two pixels, or four on one");
@@ -225,6 +225,7 @@ __device__ __forceinline__ void shade4(Pixel& a, Pixel& b, const Light (&L)[kLig
 #endif
     fetch_next_pos();
   }
+  if (kAhead && !kProbe) fetch_next_pos();  // (the walk over per-pixel lists: the next trip's positions, once this trip's are used up)
   if (skip) {
     // as instructions of this branch: plain assignments are hoisted above the test, into every trip
 #pragma unroll
@@ -1103,8 +1104,10 @@ __global__ __launch_bounds__(16 * kWalkRows, kChunked ? 4 : 1024 / (16 * kWalkRo
 #ifdef VKR_X_WALK_NOWALK
     left = 0;
 #endif
-    while (__ballot(left > 0) != 0ull) {
-      uint32_t at[4];  // byte offsets of this trip's four records
+    // Taking the next four lights off the list: their records' byte offsets, and the requests for their positions.
+    uint32_t at[4];
+    float3 pos4[4];
+    auto take_four = [&]() {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const bool has = left > e;
@@ -1119,13 +1122,25 @@ __global__ __launch_bounds__(16 * kWalkRows, kChunked ? 4 : 1024 / (16 * kWalkRo
         cur = has ? (cur & ~(0x80000000u >> pos)) : cur;
       }
       left -= 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* r = reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds.rec) + at[e]);
+        pos4[e] = make_float3(r[0], r[1], r[2]);
+      }
+    };
+    // A trip's positions are requested during the trip before (right after that trip's own have been used: they take
+    // the same registers), its colours at its start (they are needed at its end): no trip waits for LDS.
+    bool more = __ballot(left > 0) != 0ull;
+    if (more) take_four();
+    while (more) {
       Light four[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float* r = reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds.rec) + at[e]);
-        four[e] = Light{r[0], r[1], r[2], r[3], r[4], r[5]};
+        four[e] = Light{pos4[e].x, pos4[e].y, pos4[e].z, r[3], r[4], r[5]};
       }
-      shade4<false, false>(s, s, four, kc, probe, [] {}, [] {});
+      more = __ballot(left > 0) != 0ull;  // lights left after this trip, on any lane
+      shade4<false, false, 4, decltype(take_four)&, void (*)(), true>(s, s, four, kc, probe, take_four, +[] {});
     }
     if (kChunked && !last_chunk) {
 #pragma unroll
