@@ -910,6 +910,26 @@ __global__ __launch_bounds__(16 * kWalkRows, kChunked ? 4 : 1024 / (16 * kWalkRo
   if (kChunked) asm volatile("" : "+s"(width), "+s"(full_height));
   const ExactRcp by_width = exact_rcp((float)width), by_height = exact_rcp((float)full_height);
 
+  // the texels of the pixels this lane prepares are requested ahead of the table's records: the two round trips overlap
+  // (one chunk only: with several the registers are needed across the walks)
+  float home_dep[kWalkHome];
+  uint32_t home_mat[kWalkHome];
+  uint2 home_nrm[kWalkHome];
+  auto fetch_home = [&](uint32_t tq) {
+    const uint32_t xl = (tq & 15u) * kWalkHome, yl = tq >> 4;
+    const uint32_t x0 = tile_x * 32u + xl, y = tile_y * kWalkRows + yl;
+    const bool row_in = y < p.height && x0 < p.width;
+    const uint32_t lx = row_in ? x0 : tile_x * 32u, ly = row_in ? y : tile_y * kWalkRows;  // in bounds by construction
+#pragma unroll
+    for (uint32_t i = 0; i < kWalkHome; ++i) {
+      const uint32_t xi = min(lx + i, p.width - 1u);
+      home_dep[i] = *reinterpret_cast<const float*>(p.depth + (size_t)ly * p.pitch_depth + (size_t)xi * 4u);
+      home_mat[i] = *reinterpret_cast<const uint32_t*>(p.material + (size_t)ly * p.pitch_material + (size_t)xi * 4u);
+      home_nrm[i] = *reinterpret_cast<const uint2*>(p.normal + (size_t)ly * p.pitch_normal + (size_t)xi * 8u);
+    }
+  };
+  if (!kChunked) fetch_home(t);
+
   // ---- the chunk into LDS; which lights every pixel must walk; the largest |l|_1 of the others
   if (!first_chunk) __syncthreads();  // the walks over the previous chunk's records and lists have ended
   if (t == 0u) lds.lmax = 0u;
@@ -954,14 +974,12 @@ __global__ __launch_bounds__(16 * kWalkRows, kChunked ? 4 : 1024 / (16 * kWalkRo
     // a pixel's side of the test: the scaled normal and cst = margin - p.n'; kind: 0 walks none, 1 tests, 2 walks all
     float nx[kWalkHome], ny[kWalkHome], nz[kWalkHome], cst[kWalkHome];
     uint32_t kind[kWalkHome], count[kWalkHome];
+    if (kChunked) fetch_home(tq);
 #pragma unroll
     for (uint32_t i = 0; i < kWalkHome; ++i) {
       const uint32_t xi = min(lx + i, p.width - 1u);
-      const float dep = *reinterpret_cast<const float*>(p.depth + (size_t)ly * p.pitch_depth + (size_t)xi * 4u);
-      const uint32_t mat = *reinterpret_cast<const uint32_t*>(p.material + (size_t)ly * p.pitch_material + (size_t)xi * 4u);
-      const uint2 nrm = *reinterpret_cast<const uint2*>(p.normal + (size_t)ly * p.pitch_normal + (size_t)xi * 8u);
       Pixel s;
-      setup_pixel(s, p, clip_coord(xi, by_width), cy, dep, mat, nrm.x, nrm.y);
+      setup_pixel(s, p, clip_coord(xi, by_width), cy, home_dep[i], home_mat[i], home_nrm[i].x, home_nrm[i].y);
       nx[i] = s.nx, ny[i] = s.ny, nz[i] = s.nz;
       const float p1 = (fabsf(s.px) + fabsf(s.py)) + fabsf(s.pz);
       const float pn = fma_(s.pz, s.nz, fma_(s.py, s.ny, s.px * s.nx));
