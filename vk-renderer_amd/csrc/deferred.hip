@@ -875,7 +875,7 @@ struct WalkLds {
   float rec[(kWalkLights + 1u) * kWalkStride];  // first, so that a record's dwords are immediate offsets from its address; + the black light, which lanes whose list has ended walk
   uint32_t mask[kWalkWords][kWalkPixels];       // word w of pixel id's list
   uint32_t force[kWalkWords];
-  uint32_t hist[64];
+  uint32_t hist[128];
   uint32_t lmax;
   uint32_t out[kWalkPixels];                    // 8-bit results by pixel (row << 5 | column within the tile)
   uint16_t order[kWalkPixels];
@@ -933,7 +933,7 @@ __global__ __launch_bounds__(16 * kWalkRows, kChunked ? 4 : 1024 / (16 * kWalkRo
   // ---- the chunk into LDS; which lights every pixel must walk; the largest |l|_1 of the others
   if (!first_chunk) __syncthreads();  // the walks over the previous chunk's records and lists have ended
   if (t == 0u) lds.lmax = 0u;
-  if (first_chunk && t < 64u) lds.hist[t] = 0u;
+  if (first_chunk && t < 128u) lds.hist[t] = 0u;
   __syncthreads();
   if (t < kWalkLights) {  // the first four waves, one light per lane
     float4 lp = make_float4(0.0f, 0.0f, 1e18f, 0.0f), lc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1038,25 +1038,26 @@ __global__ __launch_bounds__(16 * kWalkRows, kChunked ? 4 : 1024 / (16 * kWalkRo
     }
 #pragma unroll
     for (uint32_t i = 0; i < kWalkHome; ++i) lds.length[yl * 32u + xl + i] = (uint16_t)count[i];
-    // counting sort by length / 4 (64 buckets; equal lengths stay together, their order among themselves is arbitrary
+    // counting sort by length / 2 (128 buckets; equal lengths stay together, their order among themselves is arbitrary
     // and changes nothing: a pixel's result does not depend on the lane that shades it)
     if (first_chunk) {
     uint32_t bucket[kWalkHome], within[kWalkHome];
 #pragma unroll
     for (uint32_t i = 0; i < kWalkHome; ++i) {
-      bucket[i] = min(count[i], 255u) >> 2;
+      bucket[i] = min(count[i], 255u) >> 1;
       within[i] = atomicAdd(&lds.hist[bucket[i]], 1u);
     }
     __syncthreads();
-    if (wave == 0u) {
-      const uint32_t mine = lds.hist[lane];
-      uint32_t incl = mine;
+    if (wave == 0u) {  // exclusive prefix over the 128 buckets: two per lane
+      const uint32_t a = lds.hist[2u * lane], b = lds.hist[2u * lane + 1u];
+      uint32_t incl = a + b;
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
         const uint32_t up = __shfl_up(incl, off);
         if (lane >= (uint32_t)off) incl += up;
       }
-      lds.hist[lane] = incl - mine;
+      lds.hist[2u * lane] = incl - (a + b);
+      lds.hist[2u * lane + 1u] = incl - b;
     }
     __syncthreads();
 #pragma unroll
