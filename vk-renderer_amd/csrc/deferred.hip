@@ -831,7 +831,7 @@ __global__ __launch_bounds__(64, 4) void deferred_pixel_kernel(const DeferredPar
 //
 // Lanes that walk lists of different lengths wait for the longest, and the lengths differ widely (a pixel facing
 // the bulk of the lights passes 70 % of them, one facing away 10 %), so the pixels of a tile are sorted by list
-// length (counting sort over 64 buckets in LDS) and dealt out in that order: a wave shades batches of 64 pixels of
+// length (counting sort over 128 buckets in LDS) and dealt out in that order: a wave shades batches of 64 pixels of
 // like lengths, taken so that the four waves of the workgroup end up with like totals (batches w, 7 - w, 8 + w,
 // 15 - w of the order).  Unsorted the kernel is slower than the loops that evaluate everything (2.76 against 2.25 ms).
 // One workgroup per tile of 32 x 16 or 32 x 32 pixels (four or eight waves, every lane prepares two pixels and shades
