@@ -385,6 +385,18 @@ def test_full_4k_properties(vkr, synth, oracle, ctx):
     got, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT)
     assert np.isfinite(got).all()
     got8, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R8G8B8A8_UNORM)
+    # the per-pixel light lists (the default at this light count) against the loop that evaluates every light on every pixel
+    loop, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R32G32B32A32_SFLOAT, flags=vkr.DEFERRED_WHOLE_TILE_WORKGROUPS)
+    assert np.array_equal(got.view(np.uint8), loop.view(np.uint8))
+    loop8, _ = run_deferred_gpu(vkr, ctx, case, vkr.FORMAT_R8G8B8A8_UNORM, flags=vkr.DEFERRED_WHOLE_TILE_WORKGROUPS)
+    assert np.array_equal(got8, loop8)
+    del loop, loop8
+    # and a table of 1024 lights, which the lists take in four chunks
+    c4 = dict(case, lights=synth.make_lights(1024, 77, case["camera"], case["gbuf"]))
+    lists4, _ = run_deferred_gpu(vkr, ctx, c4, vkr.FORMAT_R16G16B16A16_SFLOAT)
+    loop4, _ = run_deferred_gpu(vkr, ctx, c4, vkr.FORMAT_R16G16B16A16_SFLOAT, flags=vkr.DEFERRED_WHOLE_TILE_WORKGROUPS)
+    assert np.array_equal(lists4.view(np.uint8), loop4.view(np.uint8))
+    del lists4, loop4
     for rows in ((0, 2), (1079, 1081), (2158, 2160)):
         o32, omx = _oracles(oracle, case, rows=rows)
         _check_float(got, o32, omx, f"4K rows {rows}", 256, rows=rows)
