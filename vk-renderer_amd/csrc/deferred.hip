@@ -894,6 +894,10 @@ __global__ __launch_bounds__(16 * kWalkRows, kChunked ? 4 : 1024 / (16 * kWalkRo
   constexpr bool kIs8Bit = kOutMode == kOutRgba8 || kOutMode == kOutBgra8;
   const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
   const uint32_t tile_x = blockIdx.x, tile_y = blockIdx.y;
+#ifdef VKR_X_TIMES  // measurement builds only (tools/walk_times.py): the wall clock when a wave starts, when it has its lists and order, and when it ends
+  const unsigned long long rt_start = wall_clock64();
+  unsigned long long rt_lists = 0ull;
+#endif
   // A table of more than kWalkLights lights is taken that many at a time (kChunked).  The order in which the pixels
   // are dealt out is that of the first chunk's lists (a pixel that faces the bulk of one chunk's lights faces the bulk
   // of the next one's), so a pixel stays with its lane, and its two sums wait in LDS from one chunk to the next.
@@ -1072,6 +1076,9 @@ __global__ __launch_bounds__(16 * kWalkRows, kChunked ? 4 : 1024 / (16 * kWalkRo
     __syncthreads();
   }
 
+#ifdef VKR_X_TIMES
+  rt_lists = wall_clock64();
+#endif
   LoopConsts kc;
   asm volatile("v_mov_b32 %0, %1" : "=v"(kc.step_scale) : "s"(kStepScale));
   asm volatile("v_mov_b32 %0, %1" : "=v"(kc.step_bias) : "s"(-kEarlyOut * kStepScale));
@@ -1180,6 +1187,20 @@ __global__ __launch_bounds__(16 * kWalkRows, kChunked ? 4 : 1024 / (16 * kWalkRo
     }
   }
   }  // chunks
+#ifdef VKR_X_TIMES
+  if (lane == 0u) {
+    const uint32_t wv = (blockIdx.y * gridDim.x + blockIdx.x) * kWaves + wave;
+    if (wv < 65536u) {
+      uint32_t hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      g_wave_times[4u * wv + 0u] = rt_start;
+      g_wave_times[4u * wv + 1u] = wall_clock64();
+      g_wave_times[4u * wv + 2u] = ((unsigned long long)xcc << 32) | hw;
+      g_wave_times[4u * wv + 3u] = rt_lists;
+    }
+  }
+#endif
   if (kIs8Bit) {
     __syncthreads();
     const uint32_t xl = (t & 15u) * kWalkHome, yl = t >> 4;
