@@ -469,7 +469,7 @@ def main():
         executed = float(W) * H * (150.0 + 6.0 * L + 117.0 * L * share)
         result["roofline"].update({
             "pairs_evaluated_in_full": share, "executed_flops": executed, "executed_frac": executed / (kern_ms * 1e-3) / VALU_FP32_PEAK,
-            "frac_note": "frac counts every light on every pixel at 117 operations (SURVEY's algorithmic count); the kernel skips, exactly, the pairs "
+            "frac_note": "frac counts every light on every pixel at 117 operations (the algorithmic count, 150 + 117 L per pixel); the kernel skips, exactly, the pairs "
                          "whose light lies behind the pixel's surface (deferred.comp:43,84), so frac may exceed 1; executed_frac prices what is executed"})
 
     # ---------------------------------------------------------------- deferred: one frame in bands
