@@ -515,7 +515,8 @@ def test_non_finite_lights(vkr, synth, oracle, ctx):
         assert d.max() <= 1 and (got8[ref_nan & ~near][:, :3] == 0).all()
 
 
-@pytest.mark.parametrize("w,h,lights", [(96, 40, 24), (96, 40, 31), (96, 40, 33), (70, 50, 255), (131, 77, 256), (64, 36, 257), (50, 40, 600)])
+@pytest.mark.parametrize("w,h,lights", [(96, 40, 24), (96, 40, 31), (96, 40, 33), (70, 50, 255), (131, 77, 256), (64, 36, 257), (50, 40, 600),
+                                        (1366, 777, 40), (1290, 730, 300)])  # the last two: 32 x 32 tiles, cut off at the right and at the bottom
 def test_lists_per_pixel_give_the_bytes_of_the_loop_over_every_light(vkr, synth, ctx, w, h, lights):
     """From 24 lights up the whole-table resolve gives every pixel a list of the lights that can contribute to it (a
     one-sided test of l.n against a margin, deferred.comp:43,84) and walks only those; VKR_DEFERRED_WHOLE_TILE_WORKGROUPS

@@ -2303,10 +2303,17 @@ hipError_t launch_mode(const DeferredParams& p, const TileListOut* lists, uint32
   const dim3 fine_grid((p.width + 63u) / 64u, p.height, 1u);  // one wave per 64 pixels of a row
   const bool walk = !radius && (p.flags & 4u) == 0u && p.light_count >= kWalkMinLights;
   if (lists == nullptr && walk) {
-    // launches of few workgroups (a screen band, a small frame) take the smaller tile: twice as many workgroups to deal out
+    // Which tile.  A launch takes about (workgroups / workgroups resident + tail) workgroup lifetimes: the small tile's
+    // workgroup (four resident per CU) lives 1.1 times as long as the large one's (two per CU; half the pixels, but
+    // fewer pixels to sort make longer trips) and leaves a tail of 0.35 lifetimes against 0.5.  Fitted to 4K x 256, 270 / 540 / 2160
+    // rows: small tiles 0.207 / 0.382 / 1.42 ms, large tiles 0.217 / 0.356 / 1.345 ms.  A short launch (a screen band)
+    // and a launch whose last row of large tiles would be mostly empty take the small tile.
     const bool chunked = p.light_count > kWalkLights;
     const dim3 small_grid(grid.x, (p.height + 15u) / 16u, 1u);
-    if (fine || VKR_X_WALK_SMALL_TILES) {
+    const float cus = (float)max(cu_count, 1u);
+    const float small_cost = 1.1f * ((float)((uint64_t)small_grid.x * small_grid.y) / (4.0f * cus) + 0.35f);
+    const float large_cost = (float)((uint64_t)grid.x * grid.y) / (2.0f * cus) + 0.5f;
+    if (small_cost < large_cost || VKR_X_WALK_SMALL_TILES) {
       if (chunked)
         hipLaunchKernelGGL((deferred_walk_kernel<kOutMode, 16, true>), small_grid, dim3(256), 0, stream, p);
       else
